@@ -1,0 +1,421 @@
+"""Golden-vector generator: runs the REFERENCE's own code (imported in place from
+/root/reference, this container only) on seeded inputs from ``tests/streams.py`` and
+freezes inputs-checksums + outputs as small ``.npz`` fixtures next to this file.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+Fixtures are data only (arrays); no reference source travels.  What executes:
+  cat_*      reference ``ConstraintManager`` + ``CaT`` + ``modify_constraint_p``
+  terms      reference ``cat/constraints.py`` term functions on a fake scene
+  rms        reference ``RunningMeanStd``
+  agent      reference ``Agent`` (weights injected from tests/streams.agent_weights)
+  ppo_*      reference ``PPO()`` end to end on a recording open-loop env; locals of the
+             running ``PPO`` frame (GAE outputs, value_rms outputs, first-minibatch
+             losses/gradients) are captured with ``sys.settrace`` at fixed line numbers
+             of the reference file, noise / permutations are injected by patching
+             ``Normal.sample`` and ``torch.randperm``.
+  envfinish  the six arithmetic lines of ``CaTEnv.step`` (cat_env.py:102-107,118-121)
+             evaluated with torch (CaTEnv itself needs Isaac Sim and cannot be built).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import _ref_import as R  # noqa: E402
+import streams as S  # noqa: E402
+
+torch.set_num_threads(1)      # deterministic reductions for the frozen vectors
+torch.use_deterministic_algorithms(True)
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def t2n(x):
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+# ------------------------------------------------------------------------------ CaT streams
+class _FakeCatEnv:
+    def __init__(self, n):
+        self.num_envs = n
+        self.device = "cpu"
+        self.episode_length_buf = torch.zeros(n, dtype=torch.long)
+        self.common_step_counter = 0
+        self.cursor = 0
+        self.stream = None
+
+
+def gen_cat(tag, seed, n_envs, terms, max_ps, steps, sub=1, tau=0.95, min_p=0.0,
+            curriculum_at=None, reset_at=None):
+    cm, cfgmod, _, cu = R.load_ref_cat()
+    env = _FakeCatEnv(n_envs)
+    env.stream = S.cat_stream(seed, n_envs, terms, steps)
+
+    def make_term(name):
+        return lambda e: torch.from_numpy(np.asarray(e.stream[e.cursor][name]))
+
+    cfg = {name: cfgmod.ConstraintTermCfg(func=make_term(name), params={}, max_p=mp)
+           for (name, _, _), mp in zip(terms, max_ps)}
+    mgr = cm.ConstraintManager(cfg, env, tau=tau, min_p=min_p)
+    env.constraint_manager = mgr
+    names = [t[0] for t in terms]
+    rec = {"cstr_prob": [], "running_maxes": [], "term_max": [], "max_p": []}
+    extras_rec = {}
+    rs = np.random.RandomState(seed + 1000)
+    for t in range(steps):
+        env.cursor = t
+        env.episode_length_buf += 1
+        env.common_step_counter += 1
+        if curriculum_at is not None and t == curriculum_at:
+            # the reference's own curriculum term rewrites max_p through get/set_term_cfg
+            for name in names[:2]:
+                cu.modify_constraint_p(env, None, name, num_steps=4 * steps, init_max_p=0.25)
+        p = mgr.compute()
+        rec["cstr_prob"].append(t2n(p)[::sub].copy())
+        rec["running_maxes"].append(t2n(mgr.cat.get_running_maxes())[0].copy())
+        rec["term_max"].append(np.stack([t2n(mgr.cat.probs[n].max(1).values)[::sub] for n in names]))
+        rec["max_p"].append(np.array([mgr.get_term_cfg(n).max_p for n in names], np.float64))
+        if reset_at is not None and t in reset_at:
+            ids = np.nonzero(rs.rand(n_envs) < 0.3)[0]
+            ex = mgr.reset(torch.from_numpy(ids))
+            env.episode_length_buf[torch.from_numpy(ids)] = 0
+            extras_rec[f"reset{t}_ids"] = ids
+            extras_rec[f"reset{t}_vals"] = np.array([float(ex[k]) for k in sorted(ex)], np.float64)
+            extras_rec[f"reset{t}_keys"] = np.array(sorted(ex))
+    save(f"cat_{tag}", seed=seed, n_envs=n_envs, steps=steps, sub=sub, tau=tau, min_p=min_p,
+         term_names=np.array(names), term_widths=np.array([t[1] for t in terms]),
+         term_kinds=np.array([t[2] for t in terms]), init_max_p=np.array(max_ps, np.float64),
+         curriculum_at=-1 if curriculum_at is None else curriculum_at,
+         reset_at=np.array(sorted(reset_at) if reset_at else [], np.int64),
+         input_checksum=S.cat_stream_checksum(env.stream),
+         cstr_prob=np.stack(rec["cstr_prob"]), running_maxes=np.stack(rec["running_maxes"]),
+         term_max=np.stack(rec["term_max"]), max_p=np.stack(rec["max_p"]),
+         episode_sums=np.stack([t2n(mgr._episode_sums[n])[::sub] for n in names]),
+         cstr_mean_values=np.stack([t2n(mgr._cstr_mean_values[n])[::sub] for n in names]),
+         **extras_rec)
+
+
+def gen_curriculum():
+    _, _, _, cu = R.load_ref_cat()
+    env = types.SimpleNamespace(common_step_counter=0)
+    cfg = types.SimpleNamespace(max_p=0.25)
+    env.constraint_manager = types.SimpleNamespace(get_term_cfg=lambda n: cfg, set_term_cfg=lambda n, c: None)
+    steps = np.array([0, 1, 23, 24, 1000, 11999, 12000, 23999, 24000, 24001, 10 ** 6], np.int64)
+    table = []
+    for init in (0.25, 0.1, 1.0):
+        for s in steps:
+            env.common_step_counter = int(s)
+            table.append(cu.modify_constraint_p(env, None, "x", num_steps=24000, init_max_p=init))
+    save("curriculum", steps=steps, inits=np.array([0.25, 0.1, 1.0]), num_steps=24000,
+         max_p=np.array(table, np.float64).reshape(3, -1))
+
+
+# ------------------------------------------------------------------------------ term functions
+def gen_terms():
+    _, _, cs, _ = R.load_ref_cat()
+    from isaaclab.managers import SceneEntityCfg
+    n = 257
+    st = S.sim_state(77, n)
+    tt = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+    robot = types.SimpleNamespace(data=types.SimpleNamespace(
+        joint_pos=tt["joint_pos"], default_joint_pos=tt["default_joint_pos"], joint_vel=tt["joint_vel"],
+        joint_acc=tt["joint_acc"], applied_torque=tt["applied_torque"],
+        projected_gravity_b=tt["projected_gravity_b"], root_pos_w=tt["root_pos_w"]))
+    sensor = types.SimpleNamespace(
+        data=types.SimpleNamespace(net_forces_w_history=tt["net_forces_w_history"],
+                                   last_air_time=tt["last_air_time"]),
+        compute_first_contact=lambda dt: tt["first_contact"])
+    env = types.SimpleNamespace(
+        scene={"robot": robot, "contact_forces": sensor},
+        command_manager=types.SimpleNamespace(get_command=lambda name: tt["command"]),
+        action_manager=types.SimpleNamespace(_action=tt["action"], _prev_action=tt["prev_action"]),
+        step_dt=st["step_dt"])
+    alljoints = SceneEntityCfg("robot", joint_ids=slice(None))
+    hfe = SceneEntityCfg("robot", joint_ids=[1, 4])
+    haa = SceneEntityCfg("robot", joint_ids=[0, 3, 6, 9])
+    feet = SceneEntityCfg("contact_forces", body_ids=[3, 6, 9, 12])
+    upper = SceneEntityCfg("contact_forces", body_ids=[0, 2, 5, 8, 11])
+    out = {
+        "joint_position": cs.joint_position(env, 1.3, hfe),
+        "joint_position_when_moving_forward": cs.joint_position_when_moving_forward(env, 0.2, 0.1, haa),
+        "joint_torque": cs.joint_torque(env, 3.0, alljoints),
+        "joint_velocity": cs.joint_velocity(env, 16.0, alljoints),
+        "joint_acceleration": cs.joint_acceleration(env, 800.0, alljoints),
+        "upsidedown": cs.upsidedown(env, 0.0, SceneEntityCfg("robot")),
+        "contact": cs.contact(env, upper),
+        "base_orientation": cs.base_orientation(env, 0.1, SceneEntityCfg("robot")),
+        "air_time": cs.air_time(env, 0.25, 0.1, feet),
+        "n_foot_contact": cs.n_foot_contact(env, 2, 0.5, feet),
+        "joint_range": cs.joint_range(env, 0.4, alljoints),
+        "action_rate": cs.action_rate(env, 80.0, alljoints),
+        "foot_contact_force": cs.foot_contact_force(env, 50.0, feet),
+        "min_base_height": cs.min_base_height(env, 0.2, SceneEntityCfg("robot")),
+        "no_move": cs.no_move(env, 0.1, 4.0, alljoints),
+    }
+    save("terms", seed=77, n_envs=n, input_checksum=S.checksum(*[np.asarray(v) for v in st.values()]),
+         **{k: t2n(v) for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------ env finish
+def gen_envfinish():
+    rs = np.random.RandomState(5)
+    n = 513
+    reward = torch.from_numpy(rs.uniform(-0.2, 1.5, n).astype(np.float32))
+    p = torch.from_numpy(S.soft_dones(rs, (n,)))
+    reset = torch.from_numpy(rs.rand(n) < 0.1)
+    r = torch.clip(reward * (1.0 - p), min=0.0, max=None)     # cat_env.py:102-106
+    dones = p.clone()                                          # :107
+    ids = reset.nonzero(as_tuple=False).squeeze(-1)            # :118
+    dones[ids] = 1.0                                           # :121
+    save("envfinish", reward_in=t2n(reward), cstr_prob=t2n(p), reset=t2n(reset), reward=t2n(r), dones=t2n(dones))
+
+
+# ------------------------------------------------------------------------------ RunningMeanStd
+def gen_rms():
+    ppo = R.load_ref_ppo()
+    rs = np.random.RandomState(11)
+    vec = ppo.RunningMeanStd(shape=(45,))
+    sca = ppo.RunningMeanStd(shape=())
+    xs = (rs.standard_normal((30, 64, 45)) * rs.uniform(0.1, 5, 45) + rs.uniform(-2, 2, 45)).astype(np.float32)
+    ys = (rs.standard_normal((30, 1536)) * 3 + 1).astype(np.float32)
+    vo, so, vstate, sstate = [], [], [], []
+    for i in range(30):
+        vo.append(t2n(vec(torch.from_numpy(xs[i]))))
+        so.append(t2n(sca(torch.from_numpy(ys[i]))))
+        vstate.append(np.concatenate([t2n(vec.running_mean), t2n(vec.running_var), [float(vec.count)]]))
+        sstate.append(np.array([float(sca.running_mean), float(sca.running_var), float(sca.count)]))
+    frozen = t2n(vec(torch.from_numpy(xs[0]), update=False))
+    save("rms", seed=11, input_checksum=S.checksum(xs, ys), vec_out_last=vo[-1], vec_out_first=vo[0],
+         sca_out_last=so[-1][:64], vec_state=np.stack(vstate).astype(np.float32),
+         sca_state=np.stack(sstate).astype(np.float32), frozen_out=frozen)
+
+
+# ------------------------------------------------------------------------------ Agent
+class _SpaceEnv:
+    def __init__(self, n, d, a):
+        sp = types.SimpleNamespace
+        self.unwrapped = sp(num_envs=n, single_observation_space={"policy": sp(shape=(d,))},
+                            single_action_space=sp(shape=(a,)))
+
+
+def _ref_agent(ppo, d, a, weights):
+    ag = ppo.Agent(_SpaceEnv(1, d, a))
+    sd = ag.state_dict()
+    for k, v in weights.items():
+        sd[k] = torch.from_numpy(v)
+    ag.load_state_dict(sd)
+    return ag
+
+
+def gen_agent():
+    ppo = R.load_ref_ppo()
+    d, a, b = 45, 12, 96
+    w = S.agent_weights(3, d, a)
+    ag = _ref_agent(ppo, d, a, w)
+    keys = list(ag.state_dict().keys())
+    nparam = sum(p.numel() for p in ag.parameters())
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((b, d)).astype(np.float32)
+    eps = rs.standard_normal((b, a)).astype(np.float32)
+    from torch.distributions.normal import Normal
+    orig = Normal.sample
+    Normal.sample = lambda self, sample_shape=torch.Size(): (self.loc + self.scale * torch.from_numpy(eps)).detach()
+    try:
+        with torch.no_grad():
+            act, logp, ent, val = ag.get_action_and_value(torch.from_numpy(x))
+            act2, logp2, ent2, val2 = ag.get_action_and_value(torch.from_numpy(x), torch.from_numpy(eps * 0.3))
+            ag.obs_rms(torch.from_numpy(x * 2 + 1))  # move the normaliser off identity
+            det = ag(torch.from_numpy(x))
+    finally:
+        Normal.sample = orig
+    save("agent", weight_seed=3, input_seed=4, obs_dim=d, act_dim=a, state_keys=np.array(keys), n_params=nparam,
+         weight_checksum=S.checksum(*[w[k] for k in sorted(w)]), input_checksum=S.checksum(x, eps),
+         action=t2n(act), logprob=t2n(logp), entropy=t2n(ent), value=t2n(val),
+         logprob_given=t2n(logp2), value_given=t2n(val2), deterministic=t2n(det),
+         param_order=np.array([n for n, _ in ag.named_parameters()]))
+
+
+# ------------------------------------------------------------------------------ full PPO() runs
+class RecordingEnv:
+    """Open-loop env obeying the protocol PPO() consumes (ppo.py:158-161,186,215-230)."""
+
+    def __init__(self, stream, n, d, a):
+        self.s, self.t = stream, 0
+        sp = types.SimpleNamespace
+        self.unwrapped = sp(num_envs=n, single_observation_space={"policy": sp(shape=(d,))},
+                            single_action_space=sp(shape=(a,)))
+
+    def reset(self):
+        return {"policy": torch.from_numpy(self.s["obs0"])}, {}
+
+    def step(self, action):
+        t = self.t
+        self.t += 1
+        tn = torch.from_numpy
+        return ({"policy": tn(self.s["obs"][t])}, tn(self.s["reward"][t]), tn(self.s["dones"][t]),
+                tn(self.s["timeouts"][t]), {"log": {"Episode_Reward/track": torch.tensor(float(t))}})
+
+
+# reference line numbers inside PPO() (cleanrl/ppo.py)
+L_AFTER_GAE, L_AFTER_VRMS, L_BEFORE_CLIP, L_AFTER_UPDATE = 280, 290, 353, 356
+
+
+def run_ref_ppo(tag, seed, N, T, iters, mb, epochs, D=45, A=12, sub=1, keep_grads=True):
+    ppo = R.load_ref_ppo()
+    stream = S.env_stream(seed, T * iters, N, D)
+    weights = S.agent_weights(seed + 1, D, A)
+    rs = np.random.RandomState(seed + 2)
+    eps_all = rs.standard_normal((iters * T, N, A)).astype(np.float32)
+    perms = np.stack([rs.permutation(N * T) for _ in range(iters * epochs)]).astype(np.int64)
+    counters = {"eps": 0, "perm": 0}
+    cap = {"iters": []}
+    cur = {}
+    state = {"agent": None}
+
+    from torch.distributions.normal import Normal
+    orig_sample, orig_randperm, orig_init = Normal.sample, torch.randperm, ppo.Agent.__init__
+
+    def sample(self, sample_shape=torch.Size()):
+        e = torch.from_numpy(eps_all[counters["eps"]])
+        counters["eps"] += 1
+        return (self.loc + self.scale * e).detach()
+
+    def randperm(n, **kw):
+        p = torch.from_numpy(perms[counters["perm"]])
+        counters["perm"] += 1
+        return p
+
+    def agent_init(self, envs):
+        orig_init(self, envs)
+        sd = self.state_dict()
+        for k, v in weights.items():
+            sd[k] = torch.from_numpy(v)
+        self.load_state_dict(sd)
+        state["agent"] = self
+
+    def tracer(frame, event, arg):
+        if frame.f_code.co_name != "PPO":
+            return None
+
+        def local(frame, event, arg):
+            if event != "line":
+                return local
+            ln, loc = frame.f_lineno, frame.f_locals
+            if ln == L_AFTER_GAE:
+                cur.clear()
+                cur["advantages"], cur["returns"] = t2n(loc["advantages"]).copy(), t2n(loc["returns"]).copy()
+                cur["values"], cur["rewards"] = t2n(loc["values"]).copy(), t2n(loc["rewards"]).copy()
+                cur["dones"], cur["true_dones"] = t2n(loc["dones"]).copy(), t2n(loc["true_dones"]).copy()
+                cur["next_value"] = t2n(loc["next_value"]).reshape(-1).copy()
+                cur["next_done"] = t2n(loc["next_done"]).copy()
+                cur["next_true_done"] = t2n(loc["next_true_done"]).copy()
+                cur["logprobs"], cur["actions"] = t2n(loc["logprobs"]).copy(), t2n(loc["actions"]).copy()
+                cur["obs_last"] = t2n(loc["obs"][-1]).copy()
+                ag = loc["agent"]
+                cur["obs_rms"] = np.concatenate([t2n(ag.obs_rms.running_mean), t2n(ag.obs_rms.running_var),
+                                                 [float(ag.obs_rms.count)]])
+            elif ln == L_AFTER_VRMS:
+                ag = loc["agent"]
+                cur["b_values"], cur["b_returns"] = t2n(loc["b_values"]).copy(), t2n(loc["b_returns"]).copy()
+                cur["value_rms"] = np.array([float(ag.value_rms.running_mean), float(ag.value_rms.running_var),
+                                             float(ag.value_rms.count)])
+            elif ln == L_BEFORE_CLIP and "mb0" not in cur:
+                ag = loc["agent"]
+                g = torch.cat([p.grad.reshape(-1) for p in ag.parameters()])
+                cur["mb0"] = np.array([float(loc["loss"]), float(loc["pg_loss"]), float(loc["v_loss"]),
+                                       float(loc["entropy_loss"]), float(loc["approx_kl"]),
+                                       float(loc["old_approx_kl"]), float(loc["clipfracs"][-1]),
+                                       float(g.norm())])
+                if keep_grads:
+                    cur["mb0_grad"] = t2n(g).copy()
+                cur["mb0_inds"] = t2n(loc["mb_inds"]).copy()
+            elif ln == L_AFTER_UPDATE:
+                cur["sums"] = np.array([float(loc["sum_pg_loss"]), float(loc["sum_entropy_loss"]),
+                                        float(loc["sum_v_loss"]), float(loc["sum_surrogate_loss"])])
+                cur["lr"] = loc["optimizer"].param_groups[0]["lr"]
+                ag = loc["agent"]
+                cur["params_after"] = t2n(torch.cat([p.detach().reshape(-1) for p in ag.parameters()])).copy()
+                cap["iters"].append(dict(cur))
+            return local
+        return local
+
+    cfg = types.SimpleNamespace(
+        logger="tensorboard", learning_rate=3.0e-4, num_steps=T, num_iterations=iters, gamma=0.99,
+        gae_lambda=0.95, updates_epochs=epochs, minibatch_size=mb, clip_coef=0.2, ent_coef=0.001,
+        vf_coef=2.0, max_grad_norm=1.0, norm_adv=True, clip_vloss=True, anneal_lr=True, save_interval=10 ** 9)
+    env = RecordingEnv(stream, N, D, A)
+    Normal.sample, torch.randperm, ppo.Agent.__init__ = sample, randperm, agent_init
+    run_path = f"/tmp/golden_run_{tag}"
+    sys.settrace(tracer)
+    try:
+        ppo.PPO(env, cfg, run_path)
+    finally:
+        sys.settrace(None)
+        Normal.sample, torch.randperm, ppo.Agent.__init__ = orig_sample, orig_randperm, orig_init
+    writer = R.tensorboard_stub().last
+    scal = {}
+    for k, v, it in writer.scalars:
+        scal.setdefault(k, []).append(v)
+    out = dict(seed=seed, N=N, T=T, iters=iters, minibatch=mb, epochs=epochs, D=D, A=A, sub=sub,
+               input_checksum=S.checksum(stream["obs"], stream["reward"], stream["dones"], eps_all, perms),
+               scalar_keys=np.array(sorted(scal)),
+               scalars=np.array([scal[k] for k in sorted(scal)], np.float64))
+    psub = 97  # parameter subsample stride
+    for i, c in enumerate(cap["iters"]):
+        for k in ("advantages", "returns", "values", "logprobs"):
+            out[f"it{i}_{k}"] = c[k][:, ::sub]
+        out[f"it{i}_actions"] = c["actions"][:, ::sub][:, :, :3]
+        out[f"it{i}_next_value"] = c["next_value"][::sub]
+        out[f"it{i}_b_values"] = c["b_values"].reshape(T, N)[:, ::sub]
+        out[f"it{i}_b_returns"] = c["b_returns"].reshape(T, N)[:, ::sub]
+        out[f"it{i}_obs_last"] = c["obs_last"][::sub]
+        for k in ("obs_rms", "value_rms", "mb0", "sums"):
+            out[f"it{i}_{k}"] = c[k]
+        out[f"it{i}_lr"] = c["lr"]
+        out[f"it{i}_params_sub"] = c["params_after"][::psub]
+        out[f"it{i}_params_norm"] = float(np.linalg.norm(c["params_after"].astype(np.float64)))
+        if keep_grads and i == 0:
+            out["it0_mb0_grad_sub"] = c["mb0_grad"][::psub]
+            out["it0_mb0_grad_head"] = c["mb0_grad"][:12]
+    out["param_sub_stride"] = psub
+    save(f"ppo_{tag}", **out)
+
+
+def main():
+    assert R.have_reference(), "needs /root/reference (build container only)"
+    print("CaT streams")
+    gen_cat("small", 101, 7, S.CAT_TERMS_SMALL, [0.25, 1.0, 0.25, 1.0, 0.5], 16,
+            curriculum_at=8, reset_at={5, 11})
+    gen_cat("minp", 102, 33, S.CAT_TERMS_SMALL, [0.25, 1.0, 0.25, 1.0, 0.5], 6, min_p=0.05, tau=0.9)
+    gen_cat("solo64", 103, 64, S.CAT_TERMS_SOLO12, S.CAT_MAXP_SOLO12, 16, curriculum_at=8, reset_at={7})
+    gen_cat("solo4096", 104, 4096, S.CAT_TERMS_SOLO12, S.CAT_MAXP_SOLO12, 8, sub=16, curriculum_at=4)
+    gen_curriculum()
+    print("terms / envfinish / rms / agent")
+    gen_terms()
+    gen_envfinish()
+    gen_rms()
+    gen_agent()
+    print("PPO() runs")
+    run_ref_ppo("64x24", 201, N=64, T=24, iters=3, mb=512, epochs=5)
+    run_ref_ppo("64x48", 202, N=64, T=48, iters=1, mb=1024, epochs=1, keep_grads=False)
+    run_ref_ppo("1x1", 203, N=1, T=1, iters=1, mb=1, epochs=1, keep_grads=False)
+    run_ref_ppo("4096x24", 204, N=4096, T=24, iters=1, mb=16384, epochs=1, sub=64, keep_grads=False)
+    junk = [p for p, _, f in os.walk(R.REF_ROOT) if p.endswith("__pycache__")]
+    assert not junk, f"reference tree polluted: {junk}"
+
+
+if __name__ == "__main__":
+    main()
