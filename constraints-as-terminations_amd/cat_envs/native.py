@@ -1,0 +1,260 @@
+"""ctypes binding of libcatppo.so (include/catppo.h) - the only way the package reaches the GPU.
+
+There is NO fallback: if the shared library is missing or no gfx950 device is visible,
+``Native()`` raises.  Tensors are torch device tensors used purely as device memory
+(``data_ptr()``); the stream handed to every call is torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcatppo.so")
+
+MAX_HIDDEN = 4
+
+# catppo_term_kind
+TERM_ABS_LIMIT, TERM_ABS_DIFF_LIMIT, TERM_ABS_DIFF_LIMIT_GATE_CMDY, TERM_GREATER = 0, 1, 2, 3
+TERM_CONTACT_ANY, TERM_NORM2_LIMIT, TERM_AIR_TIME, TERM_N_FOOT_CONTACT = 4, 5, 6, 7
+TERM_ACTION_RATE, TERM_FORCE_LIMIT, TERM_LIMIT_MINUS, TERM_ABS_LIMIT_GATE_CMDNORM_LT = 8, 9, 10, 11
+
+
+class MlpShape(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32),
+                ("hidden", C.c_int32 * MAX_HIDDEN)]
+
+
+class MlpLayout(C.Structure):
+    _fields_ = [("obs_pad", C.c_int32), ("n_flat", C.c_int64), ("n_params", C.c_int64),
+                ("off_logstd", C.c_int64),
+                ("off_w", (C.c_int64 * (MAX_HIDDEN + 1)) * 2), ("off_b", (C.c_int64 * (MAX_HIDDEN + 1)) * 2),
+                ("in_dim", C.c_int32 * (MAX_HIDDEN + 1)), ("out_dim", (C.c_int32 * (MAX_HIDDEN + 1)) * 2)]
+
+
+class PpoHparams(C.Structure):
+    _fields_ = [("clip_coef", C.c_float), ("ent_coef", C.c_float), ("vf_coef", C.c_float),
+                ("norm_adv", C.c_int32), ("clip_vloss", C.c_int32), ("inv_global_batch", C.c_float),
+                ("adv_stats_external", C.c_int32)]
+
+
+class TermDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("n_ids", C.c_int32), ("ids", C.c_int32 * 16),
+                ("limit", C.c_float), ("aux", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("x_ld", C.c_int32), ("y_ld", C.c_int32)]
+
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+_SIGNATURES = {
+    "catppo_version": (C.c_int, []),
+    "catppo_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "catppo_destroy": (None, [_vp]),
+    "catppo_last_error": (C.c_char_p, [_vp]),
+    "catppo_reserve": (C.c_int, [_vp, C.c_uint64]),
+    "catppo_cat_step": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_cat_colmax": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "catppo_cat_apply": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_cat_terms": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
+    "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
+    "catppo_rms_merge": (C.c_int, [_vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
+    "catppo_rms_update": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "catppo_rms_normalize": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _f32, _vp, _i64, _vp]),
+    "catppo_mlp_layout_of": (C.c_int, [C.POINTER(MlpShape), C.POINTER(MlpLayout)]),
+    "catppo_mlp_workspace_bytes": (C.c_uint64, [C.POINTER(MlpShape), _i64]),
+    "catppo_policy_act": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_value": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp]),
+    "catppo_ppo_minibatch_grad": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp, _vp,
+                                            _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_clip_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _f64, _i64, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen libcatppo.so and attach prototypes.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"libcatppo.so not found at {path}: build it with "
+            "`python constraints-as-terminations_amd/build.py` (hipcc, gfx950). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def f32(x: float) -> float:
+    """round a Python double to fp32 the way a torch fp32 tensor op consumes a Python scalar"""
+    return C.c_float(x).value
+
+
+def shape_of(obs_dim: int, act_dim: int, hidden) -> MlpShape:
+    s = MlpShape()
+    s.obs_dim, s.act_dim, s.n_hidden = int(obs_dim), int(act_dim), len(hidden)
+    for i, h in enumerate(hidden):
+        s.hidden[i] = int(h)
+    return s
+
+
+def layout_of(shape: MlpShape) -> MlpLayout:
+    lay = MlpLayout()
+    rc = load_library().catppo_mlp_layout_of(C.byref(shape), C.byref(lay))
+    if rc != 0:
+        raise ValueError(f"unsupported MLP shape (obs={shape.obs_dim}, act={shape.act_dim}, "
+                         f"hidden={list(shape.hidden)[:shape.n_hidden]}): hidden widths must be multiples of 64, "
+                         "the last one in {64,128,256,512}, act_dim <= 16")
+    return lay
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype, name: str, contiguous: bool = True):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must live on the GPU (HIP) device")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if contiguous and not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+class Native:
+    """One catppo context bound to one HIP device."""
+
+    def __init__(self, device: Optional[torch.device] = None):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise RuntimeError("no HIP device visible: the CaT-PPO hot path runs on MI355X (gfx950) only; "
+                               "there is no CPU fallback")
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"device {device} is not a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        h = _vp()
+        rc = self.lib.catppo_create(self.device.index, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"catppo_create(device={self.device.index}) failed with {rc} "
+                               "(-3: not a gfx950 device)")
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h and getattr(self, "lib", None) is not None:
+            try:
+                self.lib.catppo_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ok(self, rc: int):
+        if rc != 0:
+            msg = self.lib.catppo_last_error(self.h)
+            raise RuntimeError(f"libcatppo error {rc}: {msg.decode() if msg else ''}")
+
+    def reserve(self, nbytes: int):
+        self._ok(self.lib.catppo_reserve(self.h, int(nbytes)))
+
+    # ------------------------------------------------------------------ CaT
+    def cat_step(self, cstr, term_off_host, term_dp_host, min_p, tau, first_call, rm, cstr_prob, ep_viol, ep_prob,
+                 reward=None, reset_mask=None, dones=None, probs=None):
+        """term_off_host: int32 ctypes array [n_terms+1]; term_dp_host: float ctypes array [n_terms]."""
+        N, K = cstr.shape
+        n_terms = len(term_dp_host)
+        self._ok(self.lib.catppo_cat_step(
+            self.h, _p(_chk(cstr, torch.float32, "cstr")), N, K, C.cast(term_off_host, _vp), n_terms,
+            C.cast(term_dp_host, _vp), f32(min_p), f32(tau), f32(1.0 - tau), int(bool(first_call)), _p(rm),
+            _p(reward), _p(reset_mask), _p(cstr_prob), _p(dones), _p(ep_viol), _p(ep_prob), _p(probs),
+            self._stream()))
+
+    def cat_colmax(self, cstr, colmax):
+        N, K = cstr.shape
+        self._ok(self.lib.catppo_cat_colmax(self.h, _p(_chk(cstr, torch.float32, "cstr")), N, K, _p(colmax),
+                                            self._stream()))
+
+    def cat_apply(self, cstr, term_off_host, term_dp_host, min_p, tau, first_call, colmax, rm, cstr_prob, ep_viol,
+                  ep_prob, reward=None, reset_mask=None, dones=None, probs=None):
+        N, K = cstr.shape
+        n_terms = len(term_dp_host)
+        self._ok(self.lib.catppo_cat_apply(
+            self.h, _p(_chk(cstr, torch.float32, "cstr")), N, K, C.cast(term_off_host, _vp), n_terms,
+            C.cast(term_dp_host, _vp), f32(min_p), f32(tau), f32(1.0 - tau), int(bool(first_call)), _p(colmax),
+            _p(rm), _p(reward), _p(reset_mask), _p(cstr_prob), _p(dones), _p(ep_viol), _p(ep_prob), _p(probs),
+            self._stream()))
+
+    def cat_terms(self, descs, n_envs, forces, H, B, command, cstr):
+        arr = (TermDesc * len(descs))(*descs)
+        self._ok(self.lib.catppo_cat_terms(self.h, arr, len(descs), int(n_envs), _p(forces), int(H), int(B),
+                                           _p(command), _p(cstr), cstr.shape[1], self._stream()))
+
+    # ------------------------------------------------------------------ GAE
+    def gae(self, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gae_lambda,
+            advantages, returns):
+        T, N = rewards.shape
+        for n, t in (("rewards", rewards), ("values", values), ("dones", dones), ("true_dones", true_dones),
+                     ("next_value", next_value), ("next_done", next_done), ("next_true_done", next_true_done),
+                     ("advantages", advantages), ("returns", returns)):
+            _chk(t, torch.float32, n)
+        self._ok(self.lib.catppo_gae(self.h, _p(rewards), _p(values), _p(dones), _p(true_dones), _p(next_value),
+                                     _p(next_done), _p(next_true_done), f32(gamma), f32(gamma * gae_lambda),
+                                     _p(advantages), _p(returns), T, N, self._stream()))
+
+    # ------------------------------------------------------------------ running mean / std
+    def rms_update(self, x, n_rows, dim, ldx, mean, var, count):
+        self._ok(self.lib.catppo_rms_update(self.h, _p(x), int(n_rows), int(dim), int(ldx), _p(mean), _p(var),
+                                            _p(count), self._stream()))
+
+    def rms_moments(self, x, n_rows, dim, ldx, sums):
+        self._ok(self.lib.catppo_rms_moments(self.h, _p(x), int(n_rows), int(dim), int(ldx),
+                                             _p(_chk(sums, torch.float64, "sums")), self._stream()))
+
+    def rms_merge(self, sums, n_total, dim, mean, var, count):
+        self._ok(self.lib.catppo_rms_merge(self.h, _p(sums), float(n_total), int(dim), _p(mean), _p(var), _p(count),
+                                           self._stream()))
+
+    def rms_normalize(self, x, n_rows, dim, ldx, mean, var, eps, out, ldo):
+        self._ok(self.lib.catppo_rms_normalize(self.h, _p(x), int(n_rows), int(dim), int(ldx), _p(mean), _p(var),
+                                               f32(eps), _p(out), int(ldo), self._stream()))
+
+    # ------------------------------------------------------------------ MLP / PPO
+    def mlp_reserve(self, shape: MlpShape, rows: int):
+        self.reserve(self.lib.catppo_mlp_workspace_bytes(C.byref(shape), int(rows)))
+
+    def policy_act(self, shape, params, x, n_rows, eps, action, logprob, value):
+        self._ok(self.lib.catppo_policy_act(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
+                                            _p(action), _p(logprob), _p(value), self._stream()))
+
+    def value(self, shape, params, x, n_rows, value):
+        self._ok(self.lib.catppo_value(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(value),
+                                       self._stream()))
+
+    def ppo_minibatch_grad(self, shape, hp: PpoHparams, params, b_obs, b_actions, b_logprobs, b_advantages,
+                           b_returns_n, b_values_n, mb_inds, vrms_mean, vrms_var, adv_stats, grad, diag):
+        _chk(mb_inds, torch.int64, "mb_inds")
+        self._ok(self.lib.catppo_ppo_minibatch_grad(
+            self.h, C.byref(shape), C.byref(hp), _p(params), _p(b_obs), _p(b_actions), _p(b_logprobs),
+            _p(b_advantages), _p(b_returns_n), _p(b_values_n), _p(mb_inds), mb_inds.numel(), _p(vrms_mean),
+            _p(vrms_var), _p(adv_stats), _p(grad), _p(diag), self._stream()))
+
+    def clip_adam(self, params, grad, exp_avg, exp_avg_sq, n_flat, max_grad_norm, lr, beta1, beta2, eps, step):
+        self._ok(self.lib.catppo_clip_adam(self.h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), int(n_flat),
+                                           f32(max_grad_norm), float(lr), float(beta1), float(beta2), float(eps),
+                                           int(step), self._stream()))

@@ -1,0 +1,68 @@
+// Internal helpers shared by the libcatppo translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/catppo.h"
+
+struct catppo_ctx {
+  int device = 0;
+  int n_cu = 256;
+  void* ws = nullptr;        // generic workspace (device)
+  uint64_t ws_bytes = 0;
+  char err[512] = {0};
+};
+
+inline int catppo_fail(catppo_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define CATPPO_CHECK_ARG(ctx, cond)                                                      \
+  do {                                                                                   \
+    if (!(cond)) return catppo_fail(ctx, CATPPO_E_ARG, "%s: bad argument: %s", __func__, #cond); \
+  } while (0)
+
+#define CATPPO_CHECK_LAUNCH(ctx)                                                         \
+  do {                                                                                   \
+    hipError_t e__ = hipGetLastError();                                                  \
+    if (e__ != hipSuccess)                                                               \
+      return catppo_fail(ctx, CATPPO_E_HIP, "%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+  } while (0)
+
+// carve `bytes` (rounded to 256) from the workspace; returns nullptr when it does not fit
+struct WsCarver {
+  char* base;
+  uint64_t cap, used = 0;
+  explicit WsCarver(catppo_ctx* c) : base(static_cast<char*>(c->ws)), cap(c->ws_bytes) {}
+  template <typename T>
+  T* take(uint64_t count) {
+    uint64_t bytes = (count * sizeof(T) + 255) & ~uint64_t(255);
+    if (used + bytes > cap) return nullptr;
+    T* p = reinterpret_cast<T*>(base + used);
+    used += bytes;
+    return p;
+  }
+};
+
+#define CATPPO_NEED_WS(ctx, ptr)                                                          \
+  do {                                                                                    \
+    if (!(ptr))                                                                           \
+      return catppo_fail(ctx, CATPPO_E_WORKSPACE, "%s: workspace too small (%llu B); call catppo_reserve", \
+                         __func__, (unsigned long long)(ctx)->ws_bytes);                  \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// NaN-propagating max (torch.max semantics): once NaN, stays NaN
+__device__ __forceinline__ float nanmax(float m, float x) { return (x > m || x != x) ? x : m; }

@@ -1,0 +1,128 @@
+// GAE backward scan over a time-major (T,N) rollout with float (soft) dones.
+//
+// Replaces the reference's Python loop of ~11 eager ops per step (cleanrl/ppo.py:251-277,
+// 264 launches at T=24) with one launch.  One lane owns VEC consecutive envs and walks t from
+// T-1 to 0; at fixed t consecutive lanes read consecutive addresses of each (T,N) plane, so
+// every load/store is a fully coalesced 256 B (VEC=1) or 1 KiB (VEC=4) wave transaction.
+// The loads of step t do not depend on the recurrence, so the unrolled loop keeps several
+// steps of loads in flight while the 5-flop dependent chain runs.
+//
+// Arithmetic is the reference's op order in unfused fp32 (this file is built with
+// -ffp-contract=off) => advantages / returns are bit-identical to the CPU torch loop.
+// Algorithmic HBM traffic: 4 reads + 2 writes = 24 B per env-step (+12 B per env bootstrap).
+#include "common.h"
+
+namespace {
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  using type = float;
+};
+template <>
+struct Vec<4> {
+  using type = float4;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    v[0] = *p;
+  } else {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+  }
+}
+template <int VEC>
+__device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 1) {
+    *p = v[0];
+  } else {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, const float* __restrict__ val,
+                                                const float* __restrict__ done, const float* __restrict__ tdone,
+                                                const float* __restrict__ next_val,
+                                                const float* __restrict__ next_done,
+                                                const float* __restrict__ next_tdone, float gamma, float gl,
+                                                float* __restrict__ adv, float* __restrict__ ret, int T,
+                                                int64_t N) {
+  const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (env >= N) return;
+  float vnext[VEC], dn[VEC], tdn[VEC], last[VEC];
+  load<VEC>(next_val + env, vnext);
+  load<VEC>(next_done + env, dn);
+  load<VEC>(next_tdone + env, tdn);
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) last[k] = 0.0f;
+
+#pragma unroll 4
+  for (int t = T - 1; t >= 0; --t) {
+    const int64_t off = (int64_t)t * N + env;
+    float r[VEC], v[VEC], d[VEC], td[VEC], a[VEC], q[VEC];
+    load<VEC>(rew + off, r);
+    load<VEC>(val + off, v);
+    load<VEC>(done + off, d);     // consumed by step t-1
+    load<VEC>(tdone + off, td);
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float nn = 1.0f - dn[k];
+      const float tn = 1.0f - tdn[k];
+      float x = gamma * vnext[k];   // GAMMA * nextvalues
+      x = x * nn;                   //   * nextnonterminal
+      x = x * tn;                   //   * true_nextnonterminal
+      float delta = r[k] + x;
+      delta = delta - v[k];
+      float c = gl * nn;            // (GAMMA*GAE_LAMBDA) * nextnonterminal
+      c = c * tn;
+      c = c * last[k];
+      last[k] = delta + c;
+      a[k] = last[k];
+      q[k] = last[k] + v[k];        // returns = advantages + values
+      vnext[k] = v[k];
+      dn[k] = d[k];
+      tdn[k] = td[k];
+    }
+    store<VEC>(adv + off, a);
+    store<VEC>(ret + off, q);
+  }
+}
+
+}  // namespace
+
+extern "C" int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,
+                          const float* true_dones, const float* next_value, const float* next_done,
+                          const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
+                          float* returns, int T, int64_t N, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, rewards && values && dones && true_dones && next_value && next_done && next_true_done);
+  CATPPO_CHECK_ARG(ctx, advantages && returns);
+  CATPPO_CHECK_ARG(ctx, T >= 1 && N >= 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // wide path only when every (T,N) row starts 16-B aligned and there are enough envs to
+  // fill the chip with 4-env lanes (256 CUs x >=8 waves)
+  const bool wide = (N % 4 == 0) && N >= (int64_t)256 * 64 * 8 * 4 / 4 && aligned16(rewards) &&
+                    aligned16(values) && aligned16(dones) && aligned16(true_dones) && aligned16(next_value) &&
+                    aligned16(next_done) && aligned16(next_true_done) && aligned16(advantages) &&
+                    aligned16(returns);
+  if (wide) {
+    const int block = 256;
+    const int64_t lanes = N / 4;
+    hipLaunchKernelGGL(gae_scan<4>, dim3((unsigned)cdiv64(lanes, block)), dim3(block), 0, s, rewards, values, dones,
+                       true_dones, next_value, next_done, next_true_done, gamma, gamma_lambda, advantages, returns,
+                       T, N);
+  } else {
+    // small N: one wave per block so that 4096 envs already spread over 64 CUs
+    const int block = N >= 65536 ? 256 : 64;
+    hipLaunchKernelGGL(gae_scan<1>, dim3((unsigned)cdiv64(N, block)), dim3(block), 0, s, rewards, values, dones,
+                       true_dones, next_value, next_done, next_true_done, gamma, gamma_lambda, advantages, returns,
+                       T, N);
+  }
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}

@@ -1,0 +1,260 @@
+// fp32-input MFMA GEMM for the actor-critic MLP (gfx950, wave64).
+//
+//   C[i,j] = epilogue( sum_k A(i,k) * B(k,j) )        i<I, j<J, k<Kc
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = the 157 TF/s fp32 matrix peak; there
+// is no TF32/xf32 on gfx950).  One 256-thread workgroup (4 waves as 2x2) owns a BMxBN tile,
+// each wave a (BM/2)x(BN/2) sub-tile = TMxTN accumulators of 32x32.  K is walked in BK=16
+// slabs, double-buffered in LDS, global->register->LDS staged so the next slab's loads are in
+// flight during the MFMAs of the current one (one barrier per slab).
+//
+// Each operand is either "K-contiguous" (element (r,k) at P[r*ld+k]: activations X[m,:],
+// weights W[n,:]) or "I-contiguous" (element (k,r) at P[k*ld+r]).  The three GEMMs of a layer:
+//   forward     Y  = X  W^T     A=X  (K-contig)  B=W  (K-contig)
+//   data grad   dX = dY W       A=dY (K-contig)  B=W  (I-contig)
+//   weight grad dW = dY^T X     A=dY (I-contig)  B=X  (I-contig)   contraction = batch (split-K)
+// so no operand is ever transposed in memory.  LDS images:
+//   K-contig: [rows][BK] with row stride BK+4 floats; a lane fetches 4 consecutive k with ONE
+//             ds_read_b128 (the 80-B row stride puts the 16 rows of every b128 lane group on
+//             16 distinct 16-B slots -> conflict-free).  MFMA step s of lane-half h uses
+//             k = 8*blk + 4*h + s: a permutation of the contraction order shared by A and B.
+//   I-contig: [BK][rows]; a lane fetches element (k, row) with ds_read_b32, the 32 lanes of a
+//             half read 32 consecutive floats -> conflict-free.
+#pragma once
+
+#include "common.h"
+
+namespace gemm {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BK = 16;
+constexpr int KC_STRIDE = BK + 4;  // floats, K-contig LDS row stride
+
+enum Epilogue {
+  EPI_BIAS_ELU = 0,  // C = elu(acc + bias[j])                       forward hidden layer
+  EPI_MUL_DELU = 1,  // C = acc * elu'(aux[i,j]) (aux = activation)  data gradient
+  EPI_PARTIAL = 2,   // C[split] = acc (+ column sums of A -> dbias) weight gradient, split-K
+};
+
+struct Operands {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;  // EPI_BIAS_ELU: [J]
+  const float* aux;   // EPI_MUL_DELU: [I, ldaux]
+  float* dbias;       // EPI_PARTIAL: [splits, I] column sums of A over the split (may be null)
+};
+
+struct Params {
+  Operands op[2];  // grouped launch: blockIdx.z % nets selects critic / actor
+  int nets;
+  int I, J, Kc;
+  int lda, ldb, ldc, ldaux;
+  int splits;            // EPI_PARTIAL: contraction split count (blockIdx.z / nets)
+  int kc_per_split;      // multiple of BK
+  int64_t c_split_stride;  // floats between consecutive split outputs
+};
+
+__device__ __forceinline__ float elu_f(float z) { return z > 0.0f ? z : (expf(z) - 1.0f); }
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
+  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
+  constexpr int WM = BM / 2, WN = BN / 2;    // wave tile
+  constexpr int A_TILE = A_KC ? BM * KC_STRIDE : BK * BM;
+  constexpr int B_TILE = B_KC ? BN * KC_STRIDE : BK * BN;
+  constexpr int A_LD4 = BM * BK / 4 / 256;   // float4 loads per thread per slab
+  constexpr int B_LD4 = BN * BK / 4 / 256;
+  static_assert(A_LD4 >= 1 && B_LD4 >= 1, "tile too small for 256 threads");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][A_TILE]
+  float* Bs = smem + 2 * A_TILE;    // [2][B_TILE]
+
+  const int net = blockIdx.z % p.nets;
+  const int split = blockIdx.z / p.nets;
+  const Operands op = p.op[net];   // by value: pointers live in SGPRs for the whole kernel
+  const int i0 = blockIdx.y * BM;
+  const int j0 = blockIdx.x * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  int k_begin = 0, k_end = p.Kc;
+  if (EPI == EPI_PARTIAL) {
+    k_begin = split * p.kc_per_split;
+    k_end = k_begin + p.kc_per_split < p.Kc ? k_begin + p.kc_per_split : p.Kc;
+  }
+
+  float4 ra[A_LD4], rb[B_LD4];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < A_LD4; ++q) {
+      const int f = tid + q * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (A_KC) {
+        const int r = f >> 2, kq = f & 3;  // 4 float4 per 16-wide row
+        const int gi = i0 + r;
+        if (gi < p.I) v = *reinterpret_cast<const float4*>(op.A + (int64_t)gi * p.lda + k0 + 4 * kq);
+      } else {
+        const int kr = f / (BM / 4), iq = f % (BM / 4);
+        const int gk = k0 + kr, gi = i0 + 4 * iq;
+        if (gk < k_end && gi + 3 < p.I) v = *reinterpret_cast<const float4*>(op.A + (int64_t)gk * p.lda + gi);
+      }
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < B_LD4; ++q) {
+      const int f = tid + q * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (B_KC) {
+        const int r = f >> 2, kq = f & 3;
+        const int gj = j0 + r;
+        if (gj < p.J) v = *reinterpret_cast<const float4*>(op.B + (int64_t)gj * p.ldb + k0 + 4 * kq);
+      } else {
+        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        const int gk = k0 + kr, gj = j0 + 4 * jq;
+        if (gk < k_end && gj + 3 < p.J) v = *reinterpret_cast<const float4*>(op.B + (int64_t)gk * p.ldb + gj);
+      }
+      rb[q] = v;
+    }
+  };
+
+  auto lstore = [&](int buf) {
+    float* a = As + buf * A_TILE;
+    float* b = Bs + buf * B_TILE;
+#pragma unroll
+    for (int q = 0; q < A_LD4; ++q) {
+      const int f = tid + q * 256;
+      if (A_KC) {
+        const int r = f >> 2, kq = f & 3;
+        *reinterpret_cast<float4*>(a + r * KC_STRIDE + 4 * kq) = ra[q];
+      } else {
+        const int kr = f / (BM / 4), iq = f % (BM / 4);
+        *reinterpret_cast<float4*>(a + kr * BM + 4 * iq) = ra[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < B_LD4; ++q) {
+      const int f = tid + q * 256;
+      if (B_KC) {
+        const int r = f >> 2, kq = f & 3;
+        *reinterpret_cast<float4*>(b + r * KC_STRIDE + 4 * kq) = rb[q];
+      } else {
+        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        *reinterpret_cast<float4*>(b + kr * BN + 4 * jq) = rb[q];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  float dbsum = 0.0f;  // EPI_PARTIAL: column sum of A for output row i0+tid (tid < BM)
+  const bool do_db = (EPI == EPI_PARTIAL) && op.dbias != nullptr && blockIdx.x == 0;
+
+  const int n_slabs = (k_end - k_begin + BK - 1) / BK;
+  if (n_slabs > 0) {
+    gload(k_begin);
+    lstore(0);
+  }
+  __syncthreads();
+
+  for (int s = 0; s < n_slabs; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < n_slabs) gload(k_begin + (s + 1) * BK);
+    const float* a = As + cur * A_TILE;
+    const float* b = Bs + cur * B_TILE;
+
+    if (EPI == EPI_PARTIAL) {
+      if (do_db && tid < BM) {
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) dbsum += a[kk * BM + tid];  // A is I-contig here
+      }
+    }
+
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      float af[TM][4], bf[TN][4];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        const int row = wm * WM + t * 32 + l31;
+        if (A_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(a + row * KC_STRIDE + 8 * blk + 4 * h);
+          af[t][0] = v.x, af[t][1] = v.y, af[t][2] = v.z, af[t][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) af[t][q] = a[(8 * blk + 4 * h + q) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        const int col = wn * WN + t * 32 + l31;
+        if (B_KC) {
+          const float4 v = *reinterpret_cast<const float4*>(b + col * KC_STRIDE + 8 * blk + 4 * h);
+          bf[t][0] = v.x, bf[t][1] = v.y, bf[t][2] = v.z, bf[t][3] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) bf[t][q] = b[(8 * blk + 4 * h + q) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][q], bf[tn][q], acc[tm][tn], 0, 0, 0);
+    }
+
+    if (s + 1 < n_slabs) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  acc[tm][tn][r] of lane: row = (r&3) + 8*(r>>2) + 4*h, col = l31 ----------
+  float* Cout = op.C;
+  if (EPI == EPI_PARTIAL) Cout += (int64_t)split * p.c_split_stride;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int gj = j0 + wn * WN + tn * 32 + l31;
+      float bias = 0.0f;
+      if (EPI == EPI_BIAS_ELU) bias = gj < p.J ? op.bias[gj] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int gi = i0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (gi < p.I && gj < p.J) {
+          float v = acc[tm][tn][r];
+          if (EPI == EPI_BIAS_ELU) {
+            v = elu_f(v + bias);
+          } else if (EPI == EPI_MUL_DELU) {
+            const float hact = op.aux[(int64_t)gi * p.ldaux + gj];
+            v = v * (hact > 0.0f ? 1.0f : hact + 1.0f);  // elu'(z) = 1 (z>0) | exp(z) = elu(z)+1
+          }
+          Cout[(int64_t)gi * p.ldc + gj] = v;
+        }
+      }
+    }
+  }
+  if (EPI == EPI_PARTIAL) {
+    if (do_db && tid < BM && i0 + tid < p.I) op.dbias[(int64_t)split * p.I + i0 + tid] = dbsum;
+  }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC>
+constexpr size_t smem_bytes() {
+  return sizeof(float) * 2 *
+         ((A_KC ? BM * KC_STRIDE : BK * BM) + (B_KC ? BN * KC_STRIDE : BK * BN));
+}
+
+}  // namespace gemm

@@ -1,0 +1,814 @@
+// Actor-critic MLP on MI355X: rollout policy step, PPO minibatch forward/loss/backward.
+//
+// Replaces cleanrl/ppo.py:71-123 (Agent) and :298-352 (minibatch update up to backward()).
+// Hidden layers run on the fp32 MFMA GEMM of gemm_f32.h (critic + actor grouped in one launch,
+// bias+ELU / ELU' fused in the epilogue).  The A-wide / 1-wide output heads, the Gaussian
+// log-prob / entropy, the clipped PPO losses AND their analytic gradients w.r.t. the last
+// hidden activations are one wave-per-row VALU kernel (head_loss): no autograd graph, no
+// (M,12) temporaries, no host sync.  Weight gradients are split-K over the batch with
+// deterministic two-stage reduction (no float atomics => run-to-run reproducible).
+#include "common.h"
+#include "gemm_f32.h"
+
+#include <cmath>
+#include <type_traits>
+
+namespace {
+
+using gemm::Operands;
+using gemm::Params;
+
+constexpr int kMaxA = 16;
+constexpr float kHalfLog2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
+constexpr float kEntConst = 1.41893853320467274178f;     // 0.5 + 0.5*log(2*pi)
+constexpr int kHeadRowsPerBlock = 64;                    // 4 waves x 16 rows
+constexpr int kGatherRows = 64;
+
+// ------------------------------------------------------------------------------- layout
+int layout_of(const catppo_mlp_shape* s, catppo_mlp_layout* L) {
+  if (!s || !L) return CATPPO_E_ARG;
+  if (s->obs_dim < 1 || s->act_dim < 1 || s->act_dim > kMaxA) return CATPPO_E_ARG;
+  if (s->n_hidden < 1 || s->n_hidden > CATPPO_MAX_HIDDEN) return CATPPO_E_ARG;
+  for (int l = 0; l < s->n_hidden; ++l)
+    if (s->hidden[l] < 64 || s->hidden[l] % 64 != 0 || s->hidden[l] > 4096) return CATPPO_E_ARG;
+  const int hl = s->hidden[s->n_hidden - 1];
+  if (hl != 64 && hl != 128 && hl != 256 && hl != 512) return CATPPO_E_ARG;  // head kernel widths
+  memset(L, 0, sizeof(*L));
+  const int nl = s->n_hidden;
+  L->obs_pad = (s->obs_dim + 15) / 16 * 16;
+  auto r4 = [](int64_t x) { return (x + 3) / 4 * 4; };
+  int64_t off = 0, np = 0;
+  L->off_logstd = off;
+  off += r4(s->act_dim);
+  np += s->act_dim;
+  for (int l = 0; l <= nl; ++l) L->in_dim[l] = l == 0 ? L->obs_pad : s->hidden[l - 1];
+  for (int net = 0; net < 2; ++net) {
+    for (int l = 0; l <= nl; ++l) {
+      const int out = l < nl ? s->hidden[l] : (net == 0 ? 1 : s->act_dim);
+      L->out_dim[net][l] = out;
+      L->off_w[net][l] = off;
+      off += r4((int64_t)out * L->in_dim[l]);
+      L->off_b[net][l] = off;
+      off += r4(out);
+      np += (int64_t)out * (l == 0 ? s->obs_dim : L->in_dim[l]) + out;
+    }
+  }
+  L->n_flat = off;
+  L->n_params = np;
+  return CATPPO_OK;
+}
+
+// ------------------------------------------------------------------------------- workspace
+struct MlpWs {
+  float* xmb;              // [M, Dp]          gathered observations
+  float* act;              // [M, A]
+  float* scal;             // [4][M]           oldlogp, adv, ret_n, val_n
+  double* adv_part;        // [nb_gather][2]
+  float* H[2][CATPPO_MAX_HIDDEN];   // activations per net / hidden layer [M, h_l]
+  float* dZ[2][CATPPO_MAX_HIDDEN];  // pre-activation gradients
+  float* wpart;            // split-K partial weight gradients (largest layer, both nets)
+  float* bpart;            // split-K partial bias gradients
+  float* head_w;           // [nb_head][(A+1)*HL]
+  float* head_s;           // [nb_head][kHeadScalars]
+  double* norm_part;       // [kNormBlocks]
+  uint64_t bytes;
+};
+constexpr int kHeadDiag = 8;
+constexpr int kNormBlocks = 256;
+inline int head_scalars(int A) { return 2 * A + 1 + kHeadDiag; }  // db4a[A], db4c, dlogstd[A], diag[8]
+
+constexpr int kMaxSplits = 64;
+
+int64_t max_wpart(const catppo_mlp_shape* s, const catppo_mlp_layout& L) {
+  int64_t m = 0;
+  for (int l = 0; l < s->n_hidden; ++l) {
+    const int64_t e = (int64_t)s->hidden[l] * L.in_dim[l];
+    m = e > m ? e : m;
+  }
+  return m;
+}
+
+bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, bool training, char* base,
+           uint64_t cap, MlpWs* w) {
+  uint64_t used = 0;
+  bool ok = true;
+  auto take = [&](uint64_t bytes) -> char* {
+    bytes = (bytes + 255) & ~uint64_t(255);
+    char* p = base ? base + used : nullptr;
+    used += bytes;
+    if (base && used > cap) ok = false;
+    return p;
+  };
+  const int nl = s->n_hidden, A = s->act_dim;
+  const int64_t nbg = cdiv64(M, kGatherRows), nbh = cdiv64(M, kHeadRowsPerBlock);
+  // reduction partials first: the non-MLP calls use the front of the workspace too, but never
+  // concurrently with an MLP call on the same stream
+  w->xmb = (float*)take(sizeof(float) * M * L.obs_pad);
+  w->act = (float*)take(sizeof(float) * M * A);
+  w->scal = (float*)take(sizeof(float) * 4 * M);
+  w->adv_part = (double*)take(sizeof(double) * 2 * nbg);
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < nl; ++l) w->H[net][l] = (float*)take(sizeof(float) * M * s->hidden[l]);
+  if (training) {
+    for (int net = 0; net < 2; ++net)
+      for (int l = 0; l < nl; ++l) w->dZ[net][l] = (float*)take(sizeof(float) * M * s->hidden[l]);
+    w->wpart = (float*)take(sizeof(float) * 2 * kMaxSplits * max_wpart(s, L));
+    w->bpart = (float*)take(sizeof(float) * 2 * kMaxSplits * 4096);
+    w->head_w = (float*)take(sizeof(float) * nbh * (A + 1) * s->hidden[nl - 1]);
+    w->head_s = (float*)take(sizeof(float) * nbh * head_scalars(A));
+  }
+  w->norm_part = (double*)take(sizeof(double) * kNormBlocks);
+  w->bytes = used;
+  return ok;
+}
+
+// ------------------------------------------------------------------------------- GEMM launch
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+void launch_gemm(const Params& p, hipStream_t s) {
+  dim3 grid((p.J + BN - 1) / BN, (p.I + BM - 1) / BM, p.nets * p.splits);
+  constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
+  gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI><<<grid, dim3(256), lds, s>>>(p);
+}
+
+// pick 128x128 tiles when they already give >= 1.5 workgroups per CU, else 64x64
+template <bool A_KC, bool B_KC, int EPI>
+void launch_gemm_auto(const Params& p, hipStream_t s) {
+  const int64_t big = (int64_t)((p.I + 127) / 128) * ((p.J + 127) / 128) * p.nets * p.splits;
+  if (big >= 384 && p.I >= 128 && p.J >= 128)
+    launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s);
+  else
+    launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s);
+}
+
+// hidden-layer forward for `nets` networks starting at net index net0
+void forward_hidden(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, const float* params, const float* x,
+                    int64_t M, const MlpWs& w, int net0, int nets, hipStream_t s) {
+  for (int l = 0; l < sh->n_hidden; ++l) {
+    Params p{};
+    p.nets = nets;
+    p.splits = 1;
+    p.I = (int)M;
+    p.J = sh->hidden[l];
+    p.Kc = L.in_dim[l];
+    p.lda = L.in_dim[l];
+    p.ldb = L.in_dim[l];
+    p.ldc = sh->hidden[l];
+    for (int n = 0; n < nets; ++n) {
+      const int net = net0 + n;
+      p.op[n].A = l == 0 ? x : w.H[net][l - 1];
+      p.op[n].B = params + L.off_w[net][l];
+      p.op[n].bias = params + L.off_b[net][l];
+      p.op[n].C = w.H[net][l];
+    }
+    launch_gemm_auto<true, true, gemm::EPI_BIAS_ELU>(p, s);
+  }
+}
+
+// ------------------------------------------------------------------------------- wave helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ------------------------------------------------------------------------------- rollout head
+// one wave per row: lane owns CPL = HL/64 columns of the last hidden activation; after the A+1
+// wave-wide dot products lane k (< A) owns action dimension k (mean, sample, log-prob term).
+template <int CPL>
+__global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__ Hc, const float* __restrict__ Ha,
+                                                       const float* __restrict__ W4c, const float* __restrict__ b4c,
+                                                       const float* __restrict__ W4a, const float* __restrict__ b4a,
+                                                       const float* __restrict__ logstd,
+                                                       const float* __restrict__ eps, int64_t M, int A,
+                                                       float* __restrict__ action, float* __restrict__ logprob,
+                                                       float* __restrict__ value) {
+  constexpr int HL = CPL * 64;
+  extern __shared__ float lds[];   // [A*HL] actor head weights
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  for (int o = threadIdx.x; o < A * HL; o += 256) lds[o] = W4a[o];
+  __syncthreads();
+  float wc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) wc[c] = W4c[lane * CPL + c];
+  const float bc = b4c[0];
+  const bool mine = lane < A;
+  const float sd = mine ? expf(logstd[lane]) : 1.0f;
+  const float var = sd * sd, lsd = logf(sd);
+  const float ba = mine ? b4a[lane] : 0.0f;
+  for (int64_t i = wave_id; i < M; i += n_waves) {
+    float dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dot = fmaf(Hc[i * HL + lane * CPL + c], wc[c], dot);
+    const float v = wave_sum(dot) + bc;
+    if (Ha != nullptr) {
+      float ha[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) ha[c] = Ha[i * HL + lane * CPL + c];
+      float mu = 0.0f;
+      for (int k = 0; k < A; ++k) {
+        float d = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], lds[k * HL + lane * CPL + c], d);
+        d = wave_sum(d);
+        if (lane == k) mu = d;
+      }
+      mu += ba;
+      float a = mu;
+      if (mine && eps != nullptr) a = mu + sd * eps[i * A + lane];   // Normal.sample(): loc + scale*N(0,1)
+      const float diff = a - mu;
+      const float term = mine ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f;
+      const float lp = wave_sum(term);
+      if (mine) action[i * A + lane] = a;
+      if (lane == 0) logprob[i] = lp;
+    }
+    if (lane == 0) value[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------- minibatch gather
+__global__ __launch_bounds__(256) void ppo_gather_kernel(const float* __restrict__ b_obs, const float* __restrict__ b_act,
+                                                         const float* __restrict__ b_logp,
+                                                         const float* __restrict__ b_adv,
+                                                         const float* __restrict__ b_ret,
+                                                         const float* __restrict__ b_val,
+                                                         const int64_t* __restrict__ inds, int64_t M, int Dp, int A,
+                                                         float* __restrict__ xmb, float* __restrict__ act,
+                                                         float* __restrict__ scal, double* __restrict__ adv_part) {
+  __shared__ int64_t s_idx[kGatherRows];
+  const int64_t r0 = (int64_t)blockIdx.x * kGatherRows;
+  const int rows = (int)((M - r0) < kGatherRows ? (M - r0) : kGatherRows);
+  if (threadIdx.x < rows) s_idx[threadIdx.x] = inds[r0 + threadIdx.x];
+  __syncthreads();
+  const int q4 = Dp / 4;
+  for (int f = threadIdx.x; f < rows * q4; f += 256) {
+    const int r = f / q4, q = f - r * q4;
+    reinterpret_cast<float4*>(xmb + (r0 + r) * Dp)[q] = reinterpret_cast<const float4*>(b_obs + s_idx[r] * Dp)[q];
+  }
+  for (int f = threadIdx.x; f < rows * A; f += 256) {
+    const int r = f / A, k = f - r * A;
+    act[(r0 + r) * A + k] = b_act[s_idx[r] * A + k];
+  }
+  if (threadIdx.x < 64) {   // wave 0: the four per-sample scalars + advantage moments
+    double a1 = 0.0, a2 = 0.0;
+    if (threadIdx.x < rows) {
+      const int64_t src = s_idx[threadIdx.x], dst = r0 + threadIdx.x;
+      const float adv = b_adv[src];
+      scal[0 * M + dst] = b_logp[src];
+      scal[1 * M + dst] = adv;
+      scal[2 * M + dst] = b_ret[src];
+      scal[3 * M + dst] = b_val[src];
+      a1 = (double)adv;
+      a2 = a1 * a1;
+    }
+    a1 = wave_sum_d(a1);
+    a2 = wave_sum_d(a2);
+    if (threadIdx.x == 0) {
+      adv_part[2 * blockIdx.x] = a1;
+      adv_part[2 * blockIdx.x + 1] = a2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- heads + PPO loss + head backward
+struct HeadArgs {
+  const float *Hc, *Ha;        // [M, HL] last hidden activations (critic, actor)
+  float *dZc, *dZa;            // [M, HL] out: gradient w.r.t. last hidden PRE-activations
+  const float *W4c, *b4c, *W4a, *b4a, *logstd;
+  const float *act, *oldlogp, *adv, *ret_n, *val_n;   // gathered minibatch
+  const double* adv_part;      // [n_adv_part][2]
+  int n_adv_part;
+  const float* adv_stats;      // external {mean, std+1e-8} or null
+  const float *vrms_mean, *vrms_var;
+  float *part_w, *part_s;      // per-block partials
+  int64_t M;
+  int A;
+  catppo_ppo_hparams hp;
+};
+
+template <int CPL>
+__global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
+  constexpr int HL = CPL * 64;
+  // LDS: [A*HL] actor head weights | [(A+1)*HL] weight-grad accumulation | [NS] scalars
+  extern __shared__ float lds[];
+  __shared__ float s_adv[2];
+  const int A = g.A;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NS = 2 * A + 1 + kHeadDiag;
+  float* s_wa = lds;
+  float* lw = lds + A * HL;               // rows 0..A-1 = dW4a, row A = dW4c
+  float* ls = lw + (A + 1) * HL;          // db4a[A], db4c, dlogstd[A], diag[8]
+
+  for (int o = threadIdx.x; o < A * HL; o += 256) s_wa[o] = g.W4a[o];
+  // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
+  if (wave == 0) {
+    if (g.hp.norm_adv && g.adv_stats == nullptr) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int b = lane; b < g.n_adv_part; b += 64) {
+        a1 += g.adv_part[2 * b];
+        a2 += g.adv_part[2 * b + 1];
+      }
+      a1 = wave_sum_d(a1);
+      a2 = wave_sum_d(a2);
+      if (lane == 0) {
+        const double n = (double)g.M;
+        const double mean = a1 / n;
+        double var = (a2 - n * mean * mean) / (n - 1.0);   // NaN for n == 1, like torch.std()
+        if (var < 0.0) var = 0.0;
+        s_adv[0] = (float)mean;
+        s_adv[1] = (float)sqrt(var) + 1e-8f;
+      }
+    } else if (lane == 0) {
+      s_adv[0] = g.adv_stats ? g.adv_stats[0] : 0.0f;
+      s_adv[1] = g.adv_stats ? g.adv_stats[1] : 1.0f;
+    }
+  }
+  __syncthreads();
+  const float adv_mean = s_adv[0], adv_den = s_adv[1];
+  const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
+  const float vden = sqrtf(g.vrms_var[0] + 1e-8f), vmean = g.vrms_mean[0];
+
+  // lane k (< A) owns action dimension k
+  const bool mine = lane < A;
+  const float sd = mine ? expf(g.logstd[lane]) : 1.0f;
+  const float var = sd * sd, lsd = logf(sd);
+  const float ba = mine ? g.b4a[lane] : 0.0f;
+  const float ent_row = wave_sum(mine ? kEntConst + lsd : 0.0f);   // entropy is state independent
+  float gba = 0.0f, gls = 0.0f;            // per-lane (per action dim) accumulators
+  float wc[CPL], gwc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) wc[c] = g.W4c[lane * CPL + c], gwc[c] = 0.0f;
+  float gwa[kMaxA][CPL];
+#pragma unroll
+  for (int k = 0; k < kMaxA; ++k)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) gwa[k][c] = 0.0f;
+  float gbc = 0.0f;
+  float d_pg = 0.0f, d_v = 0.0f, d_ent = 0.0f, d_kl = 0.0f, d_okl = 0.0f, d_cf = 0.0f;
+  const float bc = g.b4c[0];
+
+  const int64_t r0 = (int64_t)blockIdx.x * kHeadRowsPerBlock + wave * (kHeadRowsPerBlock / 4);
+  for (int rr = 0; rr < kHeadRowsPerBlock / 4; ++rr) {
+    const int64_t i = r0 + rr;
+    if (i >= g.M) break;   // wave-uniform
+    float hc[CPL], ha[CPL];
+    float dot = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      hc[c] = g.Hc[i * HL + lane * CPL + c];
+      ha[c] = g.Ha[i * HL + lane * CPL + c];
+      dot = fmaf(hc[c], wc[c], dot);
+    }
+    const float v = wave_sum(dot) + bc;
+
+    // ---- policy head, log-prob
+    float mu = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxA; ++k) {
+      if (k < A) {
+        float d = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], s_wa[k * HL + lane * CPL + c], d);
+        d = wave_sum(d);
+        if (lane == k) mu = d;
+      }
+    }
+    mu += ba;
+    const float diff = mine ? g.act[i * A + lane] - mu : 0.0f;
+    const float newlogp = wave_sum(mine ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f);
+    const float logratio = newlogp - g.oldlogp[i];
+    const float ratio = expf(logratio);
+    d_okl += -logratio;
+    d_kl += (ratio - 1.0f) - logratio;
+    d_cf += fabsf(ratio - 1.0f) > clipc ? 1.0f : 0.0f;
+
+    float adv = g.adv[i];
+    if (g.hp.norm_adv) adv = (adv - adv_mean) / adv_den;
+    const float rc = ratio < 1.0f - clipc ? 1.0f - clipc : (ratio > 1.0f + clipc ? 1.0f + clipc : ratio);
+    const float pg1 = -adv * ratio, pg2 = -adv * rc;
+    const bool inside = ratio >= 1.0f - clipc && ratio <= 1.0f + clipc;
+    float dr;   // d max(pg1,pg2) / d ratio   (torch.max splits ties 1/2 : 1/2)
+    if (pg1 > pg2) dr = -adv;
+    else if (pg1 < pg2) dr = inside ? -adv : 0.0f;
+    else dr = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);
+    d_pg += pg1 > pg2 ? pg1 : pg2;
+    const float g_logp = dr * ratio * invM;      // d loss / d newlogprob_i
+
+    // ---- value head loss
+    const float nv = (v - vmean) / vden;         // value_rms(newvalue, update=False)
+    const float R = g.ret_n[i];
+    const float e1 = nv - R;
+    float vl = e1 * e1, dnv = 2.0f * e1;
+    if (g.hp.clip_vloss) {
+      const float Vo = g.val_n[i];
+      const float dl = nv - Vo;
+      const float cl = dl < -clipc ? -clipc : (dl > clipc ? clipc : dl);
+      const float e2 = (Vo + cl) - R;
+      const float vl2 = e2 * e2;
+      const bool in2 = dl >= -clipc && dl <= clipc;
+      if (vl > vl2) dnv = 2.0f * e1;
+      else if (vl < vl2) dnv = in2 ? 2.0f * e2 : 0.0f;
+      else dnv = e1 + (in2 ? e2 : 0.0f);
+      vl = vl > vl2 ? vl : vl2;
+    }
+    d_v += 0.5f * vl;
+    d_ent += ent_row;
+    const float g_v = g.hp.vf_coef * 0.5f * dnv * invM / vden;   // d loss / d v_i
+
+    // ---- backward through the heads
+    const float gm = mine ? g_logp * diff / var : 0.0f;           // d loss / d mu_ik   (lane k)
+    if (mine) {
+      gls += g_logp * (diff * diff / var - 1.0f) - g.hp.ent_coef * invM;
+      gba += gm;
+    }
+    float dha[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) dha[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxA; ++k) {
+      if (k < A) {
+        const float gmk = __shfl(gm, k, 64);
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+          gwa[k][c] = fmaf(gmk, ha[c], gwa[k][c]);
+          dha[c] = fmaf(gmk, s_wa[k * HL + lane * CPL + c], dha[c]);
+        }
+      }
+    }
+    gbc += g_v;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      gwc[c] = fmaf(g_v, hc[c], gwc[c]);
+      const float dhc = g_v * wc[c];
+      g.dZa[i * HL + lane * CPL + c] = dha[c] * (ha[c] > 0.0f ? 1.0f : ha[c] + 1.0f);
+      g.dZc[i * HL + lane * CPL + c] = dhc * (hc[c] > 0.0f ? 1.0f : hc[c] + 1.0f);
+    }
+  }
+
+  // ---- block reduction in fixed wave order (deterministic), then one partial per block
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int k = 0; k < kMaxA; ++k)
+        if (k < A) {
+#pragma unroll
+          for (int c = 0; c < CPL; ++c) {
+            const int o = k * HL + lane * CPL + c;
+            lw[o] = w == 0 ? gwa[k][c] : lw[o] + gwa[k][c];
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        const int o = A * HL + lane * CPL + c;
+        lw[o] = w == 0 ? gwc[c] : lw[o] + gwc[c];
+      }
+      if (mine) {
+        ls[lane] = w == 0 ? gba : ls[lane] + gba;
+        ls[A + 1 + lane] = w == 0 ? gls : ls[A + 1 + lane] + gls;
+      }
+      if (lane == 0) {
+        ls[A] = w == 0 ? gbc : ls[A] + gbc;
+        float* dg = ls + 2 * A + 1;
+        const float vals[kHeadDiag] = {d_pg, d_v, d_ent, 0.0f, d_kl, d_okl, d_cf, 0.0f};
+#pragma unroll
+        for (int q = 0; q < kHeadDiag; ++q) dg[q] = w == 0 ? vals[q] : dg[q] + vals[q];
+      }
+    }
+    __syncthreads();
+  }
+  float* pw = g.part_w + (int64_t)blockIdx.x * (A + 1) * HL;
+  for (int o = threadIdx.x; o < (A + 1) * HL; o += 256) pw[o] = lw[o];
+  float* ps = g.part_s + (int64_t)blockIdx.x * NS;
+  for (int o = threadIdx.x; o < NS; o += 256) ps[o] = ls[o];
+}
+
+// ------------------------------------------------------------------------------- segmented partial reduction
+// dst[e] (+)= scale * sum_{p<n_parts} src[p*stride + e]   in fixed order.  One launch handles every segment
+// (all split-K weight/bias partials, the head partials and the diagnostics).
+constexpr int kMaxSegs = 24;
+struct Seg {
+  const float* src;
+  float* dst;
+  int64_t count;
+  int64_t stride;
+  int n_parts;
+  int mode;     // 0: dst = sum, 1: dst += sum * scale (diagnostics)
+  float scale;
+};
+struct SegTable {
+  int n;
+  Seg s[kMaxSegs];
+};
+
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
+  const Seg& sg = t.s[blockIdx.y];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < sg.count; e += (int64_t)gridDim.x * 256) {
+    float a = 0.0f;
+    for (int p = 0; p < sg.n_parts; ++p) a += sg.src[(int64_t)p * sg.stride + e];
+    if (sg.mode == 0) {
+      sg.dst[e] = a;
+    } else {
+      // diagnostics block: {pg, v, ent, loss, kl, old_kl, clipfrac, count}
+      float v = a * sg.scale;
+      if (e == 3) {
+        float pg = 0.f, vl = 0.f, en = 0.f;
+        for (int p = 0; p < sg.n_parts; ++p) {
+          pg += sg.src[(int64_t)p * sg.stride + 0];
+          vl += sg.src[(int64_t)p * sg.stride + 1];
+          en += sg.src[(int64_t)p * sg.stride + 2];
+        }
+        v = (pg - ent_coef * en + vl * vf_coef) * sg.scale;   // loss = pg - ENT*entropy + v_loss*VF
+      } else if (e == 7) {
+        v = 1.0f;                                             // number of minibatches accumulated
+      }
+      sg.dst[e] = sg.dst[e] + v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- clip + Adam
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n,
+                                                             double* __restrict__ part) {
+  __shared__ double sm[4];
+  double a = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const double v = (double)g[e];
+    a += v * v;
+  }
+  a = wave_sum_d(a);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        const double* __restrict__ norm_part, int n_part,
+                                                        float max_norm, float beta1, float beta2, float one_m_b1,
+                                                        float one_m_b2, float eps, float step_size,
+                                                        float bc2_sqrt) {
+  __shared__ float s_coef;
+  if (threadIdx.x < 64) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < n_part; b += 64) a += norm_part[b];
+    a = wave_sum_d(a);
+    if (threadIdx.x == 0) {
+      const float total = (float)sqrt(a);
+      const float c = max_norm / (total + 1e-6f);     // clip_grad_norm_: max_norm / (total_norm + 1e-6)
+      s_coef = c > 1.0f ? 1.0f : c;                   //                  clamped to 1
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float gr = g[e] * coef;
+    g[e] = gr;
+    float mm = m[e];
+    mm = mm + (gr - mm) * one_m_b1;                   // exp_avg.lerp_(grad, 1-beta1)
+    float vv = v[e] * beta2;
+    vv = vv + one_m_b2 * gr * gr;                     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    m[e] = mm;
+    v[e] = vv;
+    p[e] = p[e] + (-step_size * mm) / denom;          // param.addcdiv_(exp_avg, denom, -step_size)
+  }
+}
+
+template <typename F>
+int dispatch_cpl(int hl, F&& f) {
+  switch (hl) {
+    case 64: f(std::integral_constant<int, 1>{}); return 0;
+    case 128: f(std::integral_constant<int, 2>{}); return 0;
+    case 256: f(std::integral_constant<int, 4>{}); return 0;
+    case 512: f(std::integral_constant<int, 8>{}); return 0;
+    default: return -1;
+  }
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" int catppo_mlp_layout_of(const catppo_mlp_shape* shape, catppo_mlp_layout* out) {
+  return layout_of(shape, out);
+}
+
+extern "C" uint64_t catppo_mlp_workspace_bytes(const catppo_mlp_shape* shape, int64_t rows) {
+  catppo_mlp_layout L;
+  if (layout_of(shape, &L) != CATPPO_OK || rows < 1) return 0;
+  MlpWs w{};
+  carve(shape, L, rows, true, nullptr, 0, &w);
+  return w.bytes + 4096;
+}
+
+static int mlp_prologue(catppo_ctx* ctx, const catppo_mlp_shape* shape, int64_t M, bool training,
+                        catppo_mlp_layout* L, MlpWs* w, const char* fn) {
+  if (!ctx) return CATPPO_E_ARG;
+  if (layout_of(shape, L) != CATPPO_OK) return catppo_fail(ctx, CATPPO_E_ARG, "%s: unsupported MLP shape", fn);
+  if (M < 1 || M > (int64_t(1) << 30)) return catppo_fail(ctx, CATPPO_E_ARG, "%s: bad row count", fn);
+  if (!carve(shape, *L, M, training, static_cast<char*>(ctx->ws), ctx->ws_bytes, w))
+    return catppo_fail(ctx, CATPPO_E_WORKSPACE, "%s: workspace too small (%llu < %llu B); call catppo_reserve", fn,
+                       (unsigned long long)ctx->ws_bytes, (unsigned long long)w->bytes);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
+                                 const float* x, int64_t N, const float* eps, float* action, float* logprob,
+                                 float* value, void* stream) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, params && x && action && logprob && value);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  forward_hidden(shape, L, params, x, N, w, 0, 2, s);
+  CATPPO_CHECK_LAUNCH(ctx);
+  const int nl = shape->n_hidden, A = shape->act_dim;
+  int64_t nblk = cdiv64(N, 4);
+  if (nblk > 2048) nblk = 2048;
+  const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
+    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256),
+                       sizeof(float) * A * shape->hidden[nl - 1], s,
+                       (const float*)w.H[0][nl - 1], (const float*)w.H[1][nl - 1], params + L.off_w[0][nl],
+                       params + L.off_b[0][nl], params + L.off_w[1][nl], params + L.off_b[1][nl],
+                       params + L.off_logstd, eps, N, A, action, logprob, value);
+  });
+  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
+                            int64_t N, float* value, void* stream) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, params && x && value);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  forward_hidden(shape, L, params, x, N, w, 0, 1, s);
+  CATPPO_CHECK_LAUNCH(ctx);
+  const int nl = shape->n_hidden;
+  int64_t nblk = cdiv64(N, 4);
+  if (nblk > 2048) nblk = 2048;
+  const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
+    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256), 0, s,
+                       (const float*)w.H[0][nl - 1], (const float*)nullptr, params + L.off_w[0][nl],
+                       params + L.off_b[0][nl], (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, N, 0, (float*)nullptr, (float*)nullptr, value);
+  });
+  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape* shape,
+                                         const catppo_ppo_hparams* hp, const float* params, const float* b_obs,
+                                         const float* b_actions, const float* b_logprobs,
+                                         const float* b_advantages, const float* b_returns_n,
+                                         const float* b_values_n, const int64_t* mb_inds, int64_t M,
+                                         const float* vrms_mean, const float* vrms_var, const float* adv_stats,
+                                         float* grad, float* diag, void* stream) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, M, true, &L, &w, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, hp && params && b_obs && b_actions && b_logprobs && b_advantages && b_returns_n &&
+                            b_values_n && mb_inds && vrms_mean && vrms_var && grad && diag);
+  CATPPO_CHECK_ARG(ctx, !hp->adv_stats_external || adv_stats != nullptr);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
+  const int nbg = (int)cdiv64(M, kGatherRows), nbh = (int)cdiv64(M, kHeadRowsPerBlock);
+
+  // 1. gather the minibatch (ppo.py:300-302,314,331-337 index with mb_inds)
+  hipLaunchKernelGGL(ppo_gather_kernel, dim3(nbg), dim3(256), 0, s, b_obs, b_actions, b_logprobs, b_advantages,
+                     b_returns_n, b_values_n, mb_inds, M, L.obs_pad, A, w.xmb, w.act, w.scal, w.adv_part);
+  CATPPO_CHECK_LAUNCH(ctx);
+
+  // 2. hidden layers forward, both nets per launch
+  forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s);
+  CATPPO_CHECK_LAUNCH(ctx);
+
+  // 3. heads + losses + gradient w.r.t. last hidden pre-activations
+  HeadArgs g{};
+  g.Hc = w.H[0][nl - 1], g.Ha = w.H[1][nl - 1];
+  g.dZc = w.dZ[0][nl - 1], g.dZa = w.dZ[1][nl - 1];
+  g.W4c = params + L.off_w[0][nl], g.b4c = params + L.off_b[0][nl];
+  g.W4a = params + L.off_w[1][nl], g.b4a = params + L.off_b[1][nl];
+  g.logstd = params + L.off_logstd;
+  g.act = w.act, g.oldlogp = w.scal, g.adv = w.scal + M, g.ret_n = w.scal + 2 * M, g.val_n = w.scal + 3 * M;
+  g.adv_part = w.adv_part, g.n_adv_part = nbg;
+  g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
+  g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
+  g.part_w = w.head_w, g.part_s = w.head_s;
+  g.M = M, g.A = A, g.hp = *hp;
+  const size_t head_lds = sizeof(float) * ((size_t)A * HL + (size_t)(A + 1) * HL + head_scalars(A));
+  const int rc = dispatch_cpl(HL, [&](auto cpl) {
+    hipLaunchKernelGGL((head_loss_kernel<decltype(cpl)::value>), dim3(nbh), dim3(256), head_lds, s, g);
+  });
+  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
+  CATPPO_CHECK_LAUNCH(ctx);
+
+  // 4. backward through the hidden layers; split-K partials for every weight gradient
+  SegTable segs{};
+  auto add_seg = [&](const float* src, float* dst, int64_t count, int64_t stride, int n_parts, int mode,
+                     float scale) {
+    Seg& sg = segs.s[segs.n++];
+    sg.src = src, sg.dst = dst, sg.count = count, sg.stride = stride, sg.n_parts = n_parts, sg.mode = mode,
+    sg.scale = scale;
+  };
+  // the split-K partial buffers are reused layer after layer, so each layer's partials are folded
+  // by its own reduction launch right after its weight-gradient GEMM
+  for (int l = nl - 1; l >= 0; --l) {
+    const int out = shape->hidden[l], in = L.in_dim[l];
+    // weight gradient: dW[out,in] = dZ^T . Xin      (contraction over the M rows)
+    Params pw{};
+    pw.nets = 2;
+    pw.I = out, pw.J = in, pw.Kc = (int)M;
+    pw.lda = out, pw.ldb = in, pw.ldc = in;
+    const int tiles = ((out + 127) / 128) * ((in + 127) / 128) * 2;
+    int splits = 512 / (tiles > 0 ? tiles : 1);
+    const int max_by_rows = (int)cdiv64(M, 4 * gemm::BK);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits > kMaxSplits) splits = kMaxSplits;
+    if (splits < 1) splits = 1;
+    int per = (int)cdiv64(M, splits);
+    per = (per + gemm::BK - 1) / gemm::BK * gemm::BK;
+    splits = (int)cdiv64(M, per);
+    pw.splits = splits;
+    pw.kc_per_split = per;
+    pw.c_split_stride = 2 * (int64_t)out * in;    // [split][net][out*in]
+    for (int net = 0; net < 2; ++net) {
+      pw.op[net].A = w.dZ[net][l];
+      pw.op[net].B = l == 0 ? w.xmb : w.H[net][l - 1];
+      pw.op[net].C = w.wpart + (int64_t)net * out * in;
+      pw.op[net].dbias = w.bpart + (int64_t)net * splits * out;   // [net][split][out]
+    }
+    launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, s);
+    CATPPO_CHECK_LAUNCH(ctx);
+    segs.n = 0;
+    for (int net = 0; net < 2; ++net) {
+      add_seg(w.wpart + (int64_t)net * out * in, grad + L.off_w[net][l], (int64_t)out * in,
+              2 * (int64_t)out * in, splits, 0, 1.0f);
+      add_seg(w.bpart + (int64_t)net * splits * out, grad + L.off_b[net][l], out, out, splits, 0, 1.0f);
+    }
+    if (l == nl - 1) {
+      // head partials + diagnostics ride along with the first reduction launch
+      const int NS = head_scalars(A);
+      add_seg(w.head_w, grad + L.off_w[1][nl], (int64_t)A * HL, (int64_t)(A + 1) * HL, nbh, 0, 1.0f);
+      add_seg(w.head_w + (int64_t)A * HL, grad + L.off_w[0][nl], HL, (int64_t)(A + 1) * HL, nbh, 0, 1.0f);
+      add_seg(w.head_s, grad + L.off_b[1][nl], A, NS, nbh, 0, 1.0f);
+      add_seg(w.head_s + A, grad + L.off_b[0][nl], 1, NS, nbh, 0, 1.0f);
+      add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
+      add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, nbh, 1, hp->inv_global_batch);
+    }
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, s, segs, hp->ent_coef, hp->vf_coef);
+    CATPPO_CHECK_LAUNCH(ctx);
+    if (l > 0) {
+      // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
+      Params px{};
+      px.nets = 2;
+      px.splits = 1;
+      px.I = (int)M, px.J = in, px.Kc = out;
+      px.lda = out, px.ldb = in, px.ldc = in, px.ldaux = in;
+      for (int net = 0; net < 2; ++net) {
+        px.op[net].A = w.dZ[net][l];
+        px.op[net].B = params + L.off_w[net][l];
+        px.op[net].C = w.dZ[net][l - 1];
+        px.op[net].aux = w.H[net][l - 1];
+      }
+      launch_gemm_auto<true, false, gemm::EPI_MUL_DELU>(px, s);
+      CATPPO_CHECK_LAUNCH(ctx);
+    }
+  }
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_clip_adam(catppo_ctx* ctx, float* params, float* grad, float* exp_avg, float* exp_avg_sq,
+                                int64_t n_flat, float max_grad_norm, double lr, double beta1, double beta2,
+                                double eps, int64_t step, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, params && grad && exp_avg && exp_avg_sq && n_flat >= 1 && step >= 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WsCarver ws(ctx);
+  double* part = ws.take<double>(kNormBlocks);
+  CATPPO_NEED_WS(ctx, part);
+  int nb = (int)cdiv64(n_flat, 256 * 4);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, s, (const float*)grad, n_flat, part);
+  CATPPO_CHECK_LAUNCH(ctx);
+  // bias corrections in double on the host, like torch.optim.Adam's Python scalars
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  const float step_size = (float)(lr / bc1);
+  const float bc2_sqrt = (float)sqrt(bc2);
+  int nblk = (int)cdiv64(n_flat, 256 * 4);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, n_flat,
+                     (const double*)part, nb, max_grad_norm, (float)beta1, (float)beta2, (float)(1.0 - beta1),
+                     (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}

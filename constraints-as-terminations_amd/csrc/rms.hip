@@ -1,0 +1,180 @@
+// RunningMeanStd: column moments over a batch, Chan merge into the running state, normalise.
+//
+// Replaces cleanrl/ppo.py:12-62 (about a dozen eager launches per call; called T+1 times per
+// iteration on the (N,D) observations and twice on the (T*N,) values/returns).
+//   rms_moments_partial : per-block column sums of x and x^2 in fp64 (fixed order, no atomics)
+//   rms_moments_final   : fold the partials -> sums[2*D]                    (all-reduce point)
+//   rms_merge           : batch mean / biased variance, then the reference's fp32 Chan merge
+//   rms_normalize       : (x - mean) / sqrt(var + eps), IEEE sqrt and division
+// Built with -ffp-contract=off; the merge keeps the reference's op order:
+//   new_mean = mean + fl(fl(delta*n)/tot);  M2 = fl(fl(var*count)+fl(bvar*n)) + fl(fl(fl(delta^2*count)*n)/tot)
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__global__ __launch_bounds__(kThreads) void rms_moments_partial(const float* __restrict__ x, int64_t N, int D,
+                                                                int64_t ldx, int rows_per_block,
+                                                                double* __restrict__ partial) {
+  __shared__ double s1[kThreads], s2[kThreads];
+  const int Dc = D < kThreads ? D : kThreads;
+  const int G = kThreads / Dc;
+  const int c0 = threadIdx.x % Dc;
+  const int g = threadIdx.x / Dc;
+  for (int cb = 0; cb < D; cb += Dc) {
+    const int c = cb + c0;
+    const bool active = g < G && c < D;
+    double a = 0.0, b = 0.0;
+    if (active) {
+      for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < N; r0 += (int64_t)gridDim.x * rows_per_block) {
+        const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+        for (int64_t r = r0 + g; r < r1; r += G) {
+          const double v = (double)x[r * ldx + c];
+          a += v;
+          b += v * v;
+        }
+      }
+    }
+    s1[threadIdx.x] = a;
+    s2[threadIdx.x] = b;
+    __syncthreads();
+    if (g == 0 && c < D) {
+      for (int gg = 1; gg < G; ++gg) {
+        a += s1[gg * Dc + c0];
+        b += s2[gg * Dc + c0];
+      }
+      partial[(int64_t)blockIdx.x * 2 * D + c] = a;
+      partial[(int64_t)blockIdx.x * 2 * D + D + c] = b;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void rms_moments_final(const double* __restrict__ partial, int nblk, int D,
+                                                              double* __restrict__ sums) {
+  for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+    double a = 0.0;
+    for (int b = 0; b < nblk; ++b) a += partial[(int64_t)b * 2 * D + c];
+    sums[c] = a;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void rms_merge(const double* __restrict__ sums, double n, int D,
+                                                      float* __restrict__ mean, float* __restrict__ var,
+                                                      float* __restrict__ count) {
+  const float cnt = count[0];
+  const float nf = (float)n;                 // batch_count (Python int -> fp32 at the tensor op)
+  const float tot = cnt + nf;                // tot_count = count + batch_count
+  __syncthreads();                           // everyone has read count before it is rewritten
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const double m = sums[c] / n;
+    double v = sums[D + c] / n - m * m;      // biased variance (correction=0)
+    if (v < 0.0) v = 0.0;
+    const float bm = (float)m, bv = (float)v;
+    const float delta = bm - mean[c];
+    float t = delta * nf;                    // delta * batch_count
+    t = t / tot;                             //   / tot_count
+    const float new_mean = mean[c] + t;
+    const float m_a = var[c] * cnt;
+    const float m_b = bv * nf;
+    float d2 = delta * delta;                // torch.square(delta)
+    d2 = d2 * cnt;
+    d2 = d2 * nf;
+    d2 = d2 / tot;
+    float M2 = m_a + m_b;
+    M2 = M2 + d2;
+    mean[c] = new_mean;
+    var[c] = M2 / tot;
+  }
+  if (threadIdx.x == 0) count[0] = tot;
+}
+
+__global__ __launch_bounds__(kThreads) void rms_normalize(const float* __restrict__ x, int64_t N, int D,
+                                                          int64_t ldx, const float* __restrict__ mean,
+                                                          const float* __restrict__ var, float eps,
+                                                          float* __restrict__ out, int64_t ldo) {
+  extern __shared__ float lds[];  // [D] mean, [D] sqrt(var+eps)
+  float* s_mean = lds;
+  float* s_den = lds + D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    s_mean[c] = mean[c];
+    s_den[c] = sqrtf(var[c] + eps);
+  }
+  __syncthreads();
+  const int64_t total = N * D;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / D;
+    const int c = (int)(e - r * D);
+    const float v = x[r * ldx + c] - s_mean[c];
+    out[r * ldo + c] = v / s_den[c];
+  }
+}
+
+int launch_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, double* sums, hipStream_t s) {
+  const int Dc = D < kThreads ? D : kThreads;
+  const int G = kThreads / Dc;
+  const int rows_per_block = G * 16;
+  int nblk = (int)cdiv64(N, rows_per_block);
+  if (nblk > 512) nblk = 512;
+  WsCarver ws(ctx);
+  double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
+  CATPPO_NEED_WS(ctx, partial);
+  hipLaunchKernelGGL(rms_moments_partial, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
+  CATPPO_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(rms_moments_final, dim3(1), dim3(kThreads), 0, s, partial, nblk, D, sums);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+}  // namespace
+
+extern "C" int catppo_rms_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, double* sums,
+                                  void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, x && sums && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
+  return launch_moments(ctx, x, N, D, ldx, sums, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int catppo_rms_merge(catppo_ctx* ctx, const double* sums, double n, int D, float* mean, float* var,
+                                float* count, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, sums && mean && var && count && n >= 1.0 && D >= 1);
+  hipLaunchKernelGGL(rms_merge, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(stream), sums, n, D, mean, var,
+                     count);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, float* mean,
+                                 float* var, float* count, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, x && mean && var && count && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // the fp64 column sums live at the tail of the workspace, after the per-block partials
+  const int Dc = D < kThreads ? D : kThreads;
+  int nblk = (int)cdiv64(N, (kThreads / Dc) * 16);
+  if (nblk > 512) nblk = 512;
+  WsCarver ws(ctx);
+  double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
+  double* sums = ws.take<double>((uint64_t)2 * D);
+  CATPPO_NEED_WS(ctx, partial);
+  CATPPO_NEED_WS(ctx, sums);
+  if (int rc = launch_moments(ctx, x, N, D, ldx, sums, s)) return rc;
+  hipLaunchKernelGGL(rms_merge, dim3(1), dim3(kThreads), 0, s, sums, (double)N, D, mean, var, count);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
+                                    const float* mean, const float* var, float eps, float* out, int64_t ldo,
+                                    void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, x && mean && var && out && N >= 1 && D >= 1 && D <= 16384 && ldx >= D && ldo >= D);
+  int64_t nblk = cdiv64(N * D, kThreads * 4);
+  if (nblk > 2048) nblk = 2048;
+  hipLaunchKernelGGL(rms_normalize, dim3((unsigned)nblk), dim3(kThreads), sizeof(float) * 2 * D,
+                     static_cast<hipStream_t>(stream), x, N, D, ldx, mean, var, eps, out, ldo);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}

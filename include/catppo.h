@@ -1,0 +1,236 @@
+/*
+ * catppo.h - C ABI of libcatppo.so: the MI355X (gfx950) kernels underneath the
+ * CaT + CleanRL-PPO hot path.
+ *
+ * The reference (Gepetto/constraints-as-terminations) has no FFI: the path sits behind
+ * Python interfaces.  Each entry point below replaces a sequence of eager
+ * torch ops of the reference; the citation after "replaces:" is the reference location,
+ * relative to /root/reference/exts/cat_envs/cat_envs/tasks/utils/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch types.  All tensor memory is
+ *     caller-owned DEVICE memory (fp32 unless stated), row-major, densely packed unless a
+ *     leading dimension `ld*` is given.  The library owns only its workspace.
+ *   - every call ENQUEUES on `stream` (a hipStream_t passed as void*) and never
+ *     synchronises; no allocation after catppo_create / catppo_reserve.
+ *   - return value: 0 = ok, <0 = error (CATPPO_E_*); text via catppo_last_error(ctx).
+ *   - a ctx is bound to one device and is not thread-safe (one host thread per ctx,
+ *     like the reference's single-threaded loop).
+ *   - scalars that the reference computes in Python double and then applies to an fp32
+ *     tensor (tau, 1-tau, max_p-min_p, gamma, gamma*lambda) are passed ALREADY ROUNDED to
+ *     fp32 by the caller; the kernels use unfused IEEE fp32 (no FMA contraction, correctly
+ *     rounded division / sqrt) so that termination masks are bit-exact.
+ */
+#ifndef CATPPO_H
+#define CATPPO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CATPPO_VERSION 100 /* 0.1.0 */
+
+#define CATPPO_OK 0
+#define CATPPO_E_ARG (-1)     /* bad argument */
+#define CATPPO_E_HIP (-2)     /* HIP runtime error (launch, alloc) */
+#define CATPPO_E_NODEV (-3)   /* no gfx950 device / device index out of range */
+#define CATPPO_E_WORKSPACE (-4) /* workspace too small: call catppo_reserve first */
+
+typedef struct catppo_ctx catppo_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------- */
+int catppo_version(void);
+int catppo_create(int device, catppo_ctx** out);
+void catppo_destroy(catppo_ctx* ctx);
+const char* catppo_last_error(catppo_ctx* ctx);
+/* make sure the internal workspace holds at least `bytes` (never called implicitly while
+ * a stream capture is active; returns CATPPO_E_WORKSPACE from compute calls otherwise). */
+int catppo_reserve(catppo_ctx* ctx, uint64_t bytes);
+
+/* ---- CaT: constraints -> termination probability ------------------------------------
+ * cstr        [N,K]   constraint values of ALL terms side by side (positive = violated;
+ *                     bool terms already converted to 0/1), term t owns the columns
+ *                     [term_off[t], term_off[t+1]).
+ * term_off    [n_terms+1] int32, HOST array: column offsets, term_off[0]==0, term_off[n_terms]==K
+ * term_dp     [n_terms]  fp32, HOST array: fl32(max_p_t - min_p); the curriculum rewrites max_p
+ *                        on the host at every reset, so both arrays travel in the kernel arguments
+ *                        (n_terms <= 64)
+ * rm          [K]     running maxima (state, in/out)
+ * reward      [N]     in/out, may be NULL      r <- max(fl(r * fl(1-p)), 0)
+ * reset_mask  [N]     uint8/bool, may be NULL  dones[i] = reset ? 1 : p
+ * cstr_prob   [N]     out    p_i = max_j prob_ij
+ * dones       [N]     out, may be NULL
+ * ep_viol     [n_terms,N] in/out   += (max_{j in t} prob_ij > 0)
+ * ep_prob     [n_terms,N] in/out   += max_{j in t} prob_ij
+ * probs       [N,K]   out, may be NULL (per column probabilities, CaT.probs)
+ *
+ * replaces: cat/constraint_manager.py:39-82 (CaT.add per term, CaT.get_probs),
+ *           :213-229 (ConstraintManager.compute statistics),
+ *           cat/cat_env.py:102-107,118-121 (reward scaling, float dones, hard resets).
+ */
+int catppo_cat_step(catppo_ctx* ctx, const float* cstr, int64_t N, int K,
+                    const int32_t* term_off, int n_terms, const float* term_dp,
+                    float min_p, float tau, float one_minus_tau, int first_call,
+                    float* rm, float* reward, const uint8_t* reset_mask,
+                    float* cstr_prob, float* dones, float* ep_viol, float* ep_prob,
+                    float* probs, void* stream);
+
+/* Two-phase form for env-sharded runs (a MAX all-reduce of `colmax` goes in between):
+ *   catppo_cat_colmax : colmax[j] = max(max_i cstr[i,j], 1e-6)        (:55)
+ *   catppo_cat_apply  : running-max EMA from (all-reduced) colmax, then everything else. */
+int catppo_cat_colmax(catppo_ctx* ctx, const float* cstr, int64_t N, int K, float* colmax,
+                      void* stream);
+int catppo_cat_apply(catppo_ctx* ctx, const float* cstr, int64_t N, int K,
+                     const int32_t* term_off, int n_terms, const float* term_dp,
+                     float min_p, float tau, float one_minus_tau, int first_call,
+                     const float* colmax, float* rm, float* reward,
+                     const uint8_t* reset_mask, float* cstr_prob, float* dones,
+                     float* ep_viol, float* ep_prob, float* probs, void* stream);
+
+/* Solo12 constraint terms evaluated straight from sim-state tensors into the cstr matrix.
+ * `desc` is a host array of n_terms descriptors (see catppo_term_desc).
+ * replaces: cat/constraints.py:23-235 (C1..C15). */
+enum catppo_term_kind {
+  CATPPO_TERM_ABS_LIMIT = 0,      /* |x[:,ids]| - limit                    C1,C3,C4,C5 */
+  CATPPO_TERM_ABS_DIFF_LIMIT = 1, /* |x[:,ids]-y[:,ids]| - limit           C11 */
+  CATPPO_TERM_ABS_DIFF_LIMIT_GATE_CMDY = 2, /* (|x-y|-limit)*[|cmd_y|<dz]  C2 */
+  CATPPO_TERM_GREATER = 3,        /* x[:,col] > limit  (bool -> 0/1)       C6 */
+  CATPPO_TERM_CONTACT_ANY = 4,    /* any_b(max_h |F_hb| > thr)             C7 */
+  CATPPO_TERM_NORM2_LIMIT = 5,    /* ||x[:, :2]|| - limit                  C8 */
+  CATPPO_TERM_AIR_TIME = 6,       /* (limit-last_air)*touchdown*[|cmd|>dz] C9 */
+  CATPPO_TERM_N_FOOT_CONTACT = 7, /* |#contacts - n| * [|cmd|>minc]        C10 */
+  CATPPO_TERM_ACTION_RATE = 8,    /* |a-a_prev|/dt - limit                 C12 */
+  CATPPO_TERM_FORCE_LIMIT = 9,    /* max_h |F_hb| - limit                  C13 */
+  CATPPO_TERM_LIMIT_MINUS = 10,   /* limit - x[:,col]                      C14 */
+  CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT = 11 /* (|x|-limit)*[|cmd|<dz]     C15 */
+};
+
+typedef struct catppo_term_desc {
+  int32_t kind;          /* catppo_term_kind */
+  int32_t width;         /* output columns */
+  int32_t n_ids;         /* number of joint/body ids used (<= 16) */
+  int32_t ids[16];       /* joint ids, body ids, or ids[0] = column */
+  float limit;           /* limit / threshold */
+  float aux;             /* dead-zone / min command / desired feet / step_dt */
+  const float* x;        /* primary state tensor (N, x_ld) */
+  const float* y;        /* secondary (default_joint_pos, prev_action, first_contact as 0/1) */
+  int32_t x_ld, y_ld;
+} catppo_term_desc;
+
+/* forces: (N,H,B,3) net_forces_w_history; command: (N,3). Either may be NULL if no term
+ * uses it.  cstr [N,K] out, K = sum of widths. */
+int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
+                     const float* forces, int H, int B, const float* command, float* cstr,
+                     int K, void* stream);
+
+/* ---- GAE -------------------------------------------------------------------------------
+ * time-major (T,N) buffers; float dones in [0,1]; separate time-out mask.
+ *   nn = 1-d_{t+1}, tn = 1-td_{t+1}
+ *   delta = fl(fl(r_t + fl(fl(fl(gamma*v_{t+1})*nn)*tn)) - v_t)
+ *   A_t   = fl(delta + fl(fl(fl(gl*nn)*tn)*A_{t+1})),  ret_t = fl(A_t + v_t)
+ * replaces: cleanrl/ppo.py:251-277.  Algorithmic HBM traffic: 24 B per env-step. */
+int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,
+               const float* true_dones, const float* next_value, const float* next_done,
+               const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
+               float* returns, int T, int64_t N, void* stream);
+
+/* ---- RunningMeanStd ----------------------------------------------------------------------
+ * x [N,D] with leading dimension ldx.  mean/var [D], count [1] fp32 state.
+ *   catppo_rms_moments : sums[0:D] = sum_i x, sums[D:2D] = sum_i x^2   (fp64, deterministic)
+ *   catppo_rms_merge   : batch mean / biased var from (all-reduced) sums and total row
+ *                        count n, then the Chan merge in the reference's fp32 op order
+ *   catppo_rms_update  : moments + merge (single GPU)
+ *   catppo_rms_normalize: out = (x-mean)/sqrt(var+eps)   (out may alias x)
+ * replaces: cleanrl/ppo.py:12-62. */
+int catppo_rms_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
+                       double* sums, void* stream);
+int catppo_rms_merge(catppo_ctx* ctx, const double* sums, double n, int D, float* mean,
+                     float* var, float* count, void* stream);
+int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
+                      float* mean, float* var, float* count, void* stream);
+int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
+                         const float* mean, const float* var, float eps, float* out,
+                         int64_t ldo, void* stream);
+
+/* ---- actor-critic MLP ---------------------------------------------------------------------
+ * Two independent MLPs (critic then actor, the reference's registration order) with L
+ * hidden layers, ELU(alpha=1).  All parameters, gradients and Adam moments live in flat
+ * fp32 buffers laid out by catppo_mlp_layout (segments 16-byte aligned, first-layer rows
+ * padded from D to Dp = round_up(D,16) with zeros).
+ * replaces: cleanrl/ppo.py:71-123 (Agent), :300-354 (minibatch update). */
+#define CATPPO_MAX_HIDDEN 4
+
+typedef struct catppo_mlp_shape {
+  int32_t obs_dim;                  /* D  */
+  int32_t act_dim;                  /* A  (<= 32) */
+  int32_t n_hidden;                 /* L  (1..CATPPO_MAX_HIDDEN) */
+  int32_t hidden[CATPPO_MAX_HIDDEN]; /* widths, each a multiple of 64 */
+} catppo_mlp_shape;
+
+typedef struct catppo_mlp_layout {
+  int32_t obs_pad;                  /* Dp */
+  int64_t n_flat;                   /* total floats in the flat buffer (incl. padding) */
+  int64_t n_params;                 /* true parameter count (377,241 for the reference) */
+  int64_t off_logstd;               /* [A] */
+  /* per net (0 = critic, 1 = actor), per layer l = 0..L (L = output layer) */
+  int64_t off_w[2][CATPPO_MAX_HIDDEN + 1]; /* [out_l, in_pad_l] row-major */
+  int64_t off_b[2][CATPPO_MAX_HIDDEN + 1]; /* [out_l] */
+  int32_t in_dim[CATPPO_MAX_HIDDEN + 1];   /* padded input width of layer l */
+  int32_t out_dim[2][CATPPO_MAX_HIDDEN + 1];
+} catppo_mlp_layout;
+
+int catppo_mlp_layout_of(const catppo_mlp_shape* shape, catppo_mlp_layout* out);
+
+/* workspace bytes needed by the MLP calls for a batch of `rows` samples */
+uint64_t catppo_mlp_workspace_bytes(const catppo_mlp_shape* shape, int64_t rows);
+
+/* Rollout policy step (no grad):  x [N,Dp] normalised obs ->
+ *   action = mu + exp(logstd)*eps  (eps [N,A] supplied N(0,1) noise; NULL -> action = mu)
+ *   logprob [N], value [N].   replaces: ppo.py:104-119,208-212. */
+int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
+                      const float* x, int64_t N, const float* eps, float* action,
+                      float* logprob, float* value, void* stream);
+
+/* critic only (bootstrap value, ppo.py:252) */
+int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
+                 const float* x, int64_t N, float* value, void* stream);
+
+typedef struct catppo_ppo_hparams {
+  float clip_coef, ent_coef, vf_coef;
+  int32_t norm_adv, clip_vloss;
+  float inv_global_batch;   /* 1 / (minibatch size summed over all ranks) */
+  /* advantage normalisation statistics: if adv_stats_external != 0 the kernel reads
+   * {mean, 1/(std+1e-8)} from adv_stats (device, 2 floats; env-sharded exact mode),
+   * otherwise it computes them over this minibatch. */
+  int32_t adv_stats_external;
+} catppo_ppo_hparams;
+
+/* One minibatch: gather rows `mb_inds` of the flattened rollout buffers, forward both nets,
+ * PPO losses, backward.  Writes the flat gradient (same layout as params) and 8 diagnostics
+ * {pg_loss, v_loss, entropy, loss, approx_kl, old_approx_kl, clipfrac, 0} which are
+ * ACCUMULATED into diag[8] (zeroed by the caller once per iteration).
+ *   b_obs [B,Dp], b_actions [B,A], b_logprobs/b_advantages/b_returns_n/b_values_n [B]
+ *   mb_inds [M] int64;   value_rms {mean,var} device scalars for newvalue normalisation.
+ * replaces: ppo.py:298-352. */
+int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape* shape,
+                              const catppo_ppo_hparams* hp, const float* params,
+                              const float* b_obs, const float* b_actions,
+                              const float* b_logprobs, const float* b_advantages,
+                              const float* b_returns_n, const float* b_values_n,
+                              const int64_t* mb_inds, int64_t M, const float* vrms_mean,
+                              const float* vrms_var, const float* adv_stats, float* grad,
+                              float* diag, void* stream);
+
+/* Global-norm clip + Adam on the flat buffers (after the gradient all-reduce if sharded).
+ *   g <- g * min(1, max_norm/(||g||+1e-6));  Adam(beta1,beta2,eps), bias-corrected, `step`
+ *   counted from 1.   replaces: ppo.py:353-354 (clip_grad_norm_, optim.Adam.step). */
+int catppo_clip_adam(catppo_ctx* ctx, float* params, float* grad, float* exp_avg,
+                     float* exp_avg_sq, int64_t n_flat, float max_grad_norm, double lr,
+                     double beta1, double beta2, double eps, int64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CATPPO_H */

@@ -1,0 +1,476 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ctypes), against the oracle and
+the golden vectors of the reference.  Bit-exact for the CaT masks and GAE; stated tolerances
+for the floating-point reductions / GEMMs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import streams as S
+from oracle import cat_oracle as CO
+from oracle import ppo_oracle as PO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from cat_envs import native
+    n = native.Native()
+    return n
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def pack_stream_step(step, terms):
+    cols = []
+    for name, width, kind in terms:
+        v = np.asarray(step[name])
+        v = v.astype(np.float32)
+        cols.append(v.reshape(v.shape[0], -1))
+    return np.concatenate(cols, axis=1)
+
+
+def term_meta(terms, max_p, min_p):
+    from cat_envs import native
+    off = np.concatenate([[0], np.cumsum([w for _, w, _ in terms])]).astype(np.int32)
+    off_c = (C.c_int32 * len(off))(*off.tolist())
+    dp = (C.c_float * len(terms))(*[native.f32(p - min_p) for p in max_p])
+    return off, off_c, dp
+
+
+@pytest.mark.parametrize("tag", ["small", "minp", "solo64", "solo4096"])
+def test_cat_step_bit_exact_vs_reference_golden(nat, golden, tag):
+    """catppo_cat_step on the same streams the reference ConstraintManager consumed."""
+    g = golden(f"cat_{tag}")
+    n, steps, sub = int(g["n_envs"]), int(g["steps"]), int(g["sub"])
+    terms = list(zip([str(x) for x in g["term_names"]], [int(w) for w in g["term_widths"]],
+                     [str(k) for k in g["term_kinds"]]))
+    tau, min_p = float(g["tau"]), float(g["min_p"])
+    stream = S.cat_stream(int(g["seed"]), n, terms, steps)
+    K = sum(w for _, w, _ in terms)
+    nt = len(terms)
+    rm = torch.zeros(K, device="cuda")
+    prob = torch.zeros(n, device="cuda")
+    viol = torch.zeros(nt, n, device="cuda")
+    eprob = torch.zeros(nt, n, device="cuda")
+    probs = torch.zeros(n, K, device="cuda")
+    ep_len = np.zeros(n, np.int64)
+    rs = np.random.RandomState(int(g["seed"]) + 1000)
+    reset_at = set(int(x) for x in g["reset_at"])
+    orc = CO.ConstraintManagerOracle([t[0] for t in terms], n, tau=tau, min_p=min_p)
+    for t in range(steps):
+        ep_len += 1
+        max_p = [float(x) for x in g["max_p"][t]]
+        off, off_c, dp = term_meta(terms, max_p, min_p)
+        cstr = dev(pack_stream_step(stream[t], terms))
+        nat.cat_step(cstr, off_c, dp, min_p, tau, t == 0, rm, prob, viol, eprob, probs=probs)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(prob.cpu().numpy()[::sub], g["cstr_prob"][t])
+        np.testing.assert_array_equal(rm.cpu().numpy(), g["running_maxes"][t])
+        pr = probs.cpu().numpy()
+        tm = np.stack([pr[:, off[i]:off[i + 1]].max(1)[::sub] for i in range(nt)])
+        np.testing.assert_array_equal(tm, g["term_max"][t])
+        # and the full (un-subsampled) matrices against the oracle
+        po = orc.compute(stream[t], {nm: mp for (nm, _, _), mp in zip(terms, max_p)})
+        np.testing.assert_array_equal(prob.cpu().numpy(), po)
+        np.testing.assert_array_equal(pr, np.concatenate([orc.cat.probs[nm] for nm, _, _ in terms], 1))
+        if t in reset_at:   # ConstraintManager.reset zeroes the stats of the reset envs
+            ids = np.nonzero(rs.rand(n) < 0.3)[0]
+            idt = torch.from_numpy(ids).cuda()
+            L = torch.from_numpy(ep_len).cuda()[idt].float()
+            vals = []
+            for i, (nm, _, _) in enumerate(terms):
+                vals.append((nm, float((viol[i, idt] / L).mean() * 100), float((eprob[i, idt] / L).mean())))
+            exp = dict(zip([str(k) for k in g[f"reset{t}_keys"]], g[f"reset{t}_vals"]))
+            for nm, v, p in vals:
+                np.testing.assert_allclose(v, exp[f"Episode_Constraint_violation/{nm}"], rtol=1e-5, atol=1e-6)
+                np.testing.assert_allclose(p, exp[f"Episode_Constraint_probability/{nm}"], rtol=1e-5, atol=1e-7)
+            viol[:, idt] = 0
+            eprob[:, idt] = 0
+            orc.reset(ids, ep_len)
+            ep_len[ids] = 0
+    np.testing.assert_array_equal(viol.cpu().numpy()[:, ::sub], g["episode_sums"])
+    np.testing.assert_array_equal(eprob.cpu().numpy()[:, ::sub], g["cstr_mean_values"])
+
+
+def test_cat_two_phase_equals_fused_and_env_finish(nat, golden):
+    """colmax -> (all-reduce point) -> apply == fused step; reward/dones epilogue vs golden."""
+    terms = S.CAT_TERMS_SOLO12
+    n, K = 1000, sum(w for _, w, _ in terms)     # ragged: not a multiple of the 32-env tile
+    stream = S.cat_stream(9, n, terms, 3)
+    off, off_c, dp = term_meta(terms, S.CAT_MAXP_SOLO12, 0.0)
+    nt = len(terms)
+    state = []
+    for mode in (0, 1):
+        rm = torch.zeros(K, device="cuda")
+        prob, dones = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        viol, eprob = torch.zeros(nt, n, device="cuda"), torch.zeros(nt, n, device="cuda")
+        colmax = torch.zeros(K, device="cuda")
+        rs = np.random.RandomState(3)
+        outs = []
+        for t in range(3):
+            cstr = dev(pack_stream_step(stream[t], terms))
+            reward = dev(rs.uniform(-0.2, 1.5, n).astype(np.float32))
+            r_in = reward.clone()
+            reset = dev(rs.rand(n) < 0.1)
+            if mode == 0:
+                nat.cat_step(cstr, off_c, dp, 0.0, 0.95, t == 0, rm, prob, viol, eprob, reward=reward,
+                             reset_mask=reset, dones=dones)
+            else:
+                nat.cat_colmax(cstr, colmax)
+                nat.cat_apply(cstr, off_c, dp, 0.0, 0.95, t == 0, colmax, rm, prob, viol, eprob, reward=reward,
+                              reset_mask=reset, dones=dones)
+            torch.cuda.synchronize()
+            r_exp, d_exp = CO.env_finish(r_in.cpu().numpy(), prob.cpu().numpy(), reset.cpu().numpy())
+            np.testing.assert_array_equal(reward.cpu().numpy(), r_exp)
+            np.testing.assert_array_equal(dones.cpu().numpy(), d_exp)
+            outs.append((prob.cpu().numpy().copy(), rm.cpu().numpy().copy()))
+        state.append((outs, viol.cpu().numpy(), eprob.cpu().numpy()))
+    for (a, b) in zip(state[0][0], state[1][0]):
+        np.testing.assert_array_equal(a[0], b[0])
+        np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(state[0][1], state[1][1])
+    np.testing.assert_array_equal(state[0][2], state[1][2])
+    g = golden("envfinish")
+    n2 = g["reward_in"].shape[0]
+    # one-term manager whose probability equals the golden cstr_prob: c = p (rm=1, dp=1)
+    p = g["cstr_prob"]
+    cstr = dev(np.where(p > 0, p, -1.0).astype(np.float32)[:, None])
+    rm = torch.ones(1, device="cuda")
+    prob, dones = torch.zeros(n2, device="cuda"), torch.zeros(n2, device="cuda")
+    viol, eprob = torch.zeros(1, n2, device="cuda"), torch.zeros(1, n2, device="cuda")
+    reward = dev(g["reward_in"])
+    off1, dp1 = (C.c_int32 * 2)(0, 1), (C.c_float * 1)(1.0)
+    colmax = torch.ones(1, device="cuda")
+    nat.cat_apply(cstr, off1, dp1, 0.0, 1.0, False, colmax, rm, prob, viol, eprob, reward=reward,
+                  reset_mask=dev(g["reset"]), dones=dones)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(prob.cpu().numpy(), p)
+    np.testing.assert_array_equal(reward.cpu().numpy(), g["reward"])
+    np.testing.assert_array_equal(dones.cpu().numpy(), g["dones"])
+
+
+def _term_descs(native, st_dev, feet, upper):
+    def d(kind, width, ids, limit=0.0, aux=0.0, x=None, y=None):
+        t = native.TermDesc()
+        t.kind, t.width, t.n_ids, t.limit, t.aux = kind, width, len(ids), limit, aux
+        for i, v in enumerate(ids):
+            t.ids[i] = v
+        if x is not None:
+            t.x, t.x_ld = x.data_ptr(), x.shape[1]
+        if y is not None:
+            t.y, t.y_ld = y.data_ptr(), y.shape[1]
+        return t
+    s = st_dev
+    alljoints = list(range(12))
+    n = native
+    return [
+        ("joint_position", d(n.TERM_ABS_LIMIT, 2, [1, 4], 1.3, x=s["joint_pos"])),
+        ("joint_position_when_moving_forward", d(n.TERM_ABS_DIFF_LIMIT_GATE_CMDY, 4, [0, 3, 6, 9], 0.2, 0.1,
+                                                  x=s["joint_pos"], y=s["default_joint_pos"])),
+        ("joint_torque", d(n.TERM_ABS_LIMIT, 12, alljoints, 3.0, x=s["applied_torque"])),
+        ("joint_velocity", d(n.TERM_ABS_LIMIT, 12, alljoints, 16.0, x=s["joint_vel"])),
+        ("joint_acceleration", d(n.TERM_ABS_LIMIT, 12, alljoints, 800.0, x=s["joint_acc"])),
+        ("upsidedown", d(n.TERM_GREATER, 1, [2], 0.0, x=s["projected_gravity_b"])),
+        ("contact", d(n.TERM_CONTACT_ANY, 1, upper, 1.0)),
+        ("base_orientation", d(n.TERM_NORM2_LIMIT, 1, [], 0.1, x=s["projected_gravity_b"])),
+        ("air_time", d(n.TERM_AIR_TIME, 4, feet, 0.25, 0.1, x=s["last_air_time"], y=s["first_contact"])),
+        ("n_foot_contact", d(n.TERM_N_FOOT_CONTACT, 1, feet, 2, 0.5)),
+        ("joint_range", d(n.TERM_ABS_DIFF_LIMIT, 12, alljoints, 0.4, x=s["joint_pos"], y=s["default_joint_pos"])),
+        ("action_rate", d(n.TERM_ACTION_RATE, 12, alljoints, 80.0, native.f32(0.02), x=s["action"], y=s["prev_action"])),
+        ("foot_contact_force", d(n.TERM_FORCE_LIMIT, 4, feet, 50.0)),
+        ("min_base_height", d(n.TERM_LIMIT_MINUS, 1, [2], 0.2, x=s["root_pos_w"])),
+        ("no_move", d(n.TERM_ABS_LIMIT_GATE_CMDNORM_LT, 12, alljoints, 4.0, 0.1, x=s["joint_vel"])),
+    ]
+
+
+def test_constraint_terms_vs_reference_golden(nat, golden):
+    from cat_envs import native
+    g = golden("terms")
+    n = int(g["n_envs"])
+    st = S.sim_state(int(g["seed"]), n)
+    sd = {k: dev(v, torch.float32) for k, v in st.items() if isinstance(v, np.ndarray)}
+    feet, upper = [3, 6, 9, 12], [0, 2, 5, 8, 11]
+    named = _term_descs(native, sd, feet, upper)
+    K = sum(t.width for _, t in named)
+    cstr = torch.full((n, K), 123.0, device="cuda")
+    nat.cat_terms([t for _, t in named], n, sd["net_forces_w_history"], 3, 13, sd["command"], cstr)
+    torch.cuda.synchronize()
+    out = cstr.cpu().numpy()
+    c = 0
+    loose = {"base_orientation", "foot_contact_force"}
+    for name, t in named:
+        got = out[:, c:c + t.width]
+        c += t.width
+        exp = np.asarray(g[name]).astype(np.float32).reshape(n, -1)
+        if name in loose:
+            np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-5, err_msg=name)
+        else:
+            np.testing.assert_array_equal(got, exp, err_msg=name)
+
+
+@pytest.mark.parametrize("T,N,seed", [(1, 1, 1), (24, 64, 2), (48, 4096, 3), (5, 1000, 4), (24, 262144, 5)])
+def test_gae_bit_exact(nat, T, N, seed):
+    x = S.gae_inputs(seed, T, N)
+    d = {k: dev(v) for k, v in x.items()}
+    adv, ret = torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda")
+    nat.gae(d["rewards"], d["values"], d["dones"], d["true_dones"], d["next_value"], d["next_done"],
+            d["next_true_done"], 0.99, 0.95, adv, ret)
+    torch.cuda.synchronize()
+    a, r = PO.gae_numpy_exact(x["rewards"], x["values"], x["dones"], x["true_dones"], x["next_value"], x["next_done"],
+                              x["next_true_done"], 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy(), a)
+    np.testing.assert_array_equal(ret.cpu().numpy(), r)
+
+
+@pytest.mark.parametrize("tag", ["64x24", "64x48", "4096x24"])
+def test_gae_vs_reference_ppo_run(nat, golden, tag):
+    """advantages/returns captured inside the running reference PPO() (float dones, time-outs)."""
+    g = golden(f"ppo_{tag}")
+    N, T, D, sub, seed = int(g["N"]), int(g["T"]), int(g["D"]), int(g["sub"]), int(g["seed"])
+    s = S.env_stream(seed, T * int(g["iters"]), N, D)
+    # iteration 0: rewards/dones/timeouts of steps 0..T-1; dones[t] is the done of the PREVIOUS env step
+    dones = np.concatenate([np.zeros((1, N), np.float32), s["dones"][:T - 1]])
+    tdones = np.concatenate([np.zeros((1, N), np.float32), s["timeouts"][:T - 1].astype(np.float32)])
+    if sub != 1:
+        pytest.skip("values of the subsampled run are not stored densely")
+    vals = g["it0_values"]
+    adv, ret = torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda")
+    nat.gae(dev(s["reward"][:T]), dev(vals), dev(dones), dev(tdones), dev(g["it0_next_value"]),
+            dev(s["dones"][T - 1]), dev(s["timeouts"][T - 1].astype(np.float32)), 0.99, 0.95, adv, ret)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(adv.cpu().numpy(), g["it0_advantages"])
+    np.testing.assert_array_equal(ret.cpu().numpy(), g["it0_returns"])
+
+
+def test_running_mean_std_vs_reference_golden(nat, golden):
+    g = golden("rms")
+    rs = np.random.RandomState(int(g["seed"]))
+    xs = (rs.standard_normal((30, 64, 45)) * rs.uniform(0.1, 5, 45) + rs.uniform(-2, 2, 45)).astype(np.float32)
+    ys = (rs.standard_normal((30, 1536)) * 3 + 1).astype(np.float32)
+    mean, var, cnt = torch.zeros(45, device="cuda"), torch.ones(45, device="cuda"), torch.ones(1, device="cuda")
+    smean, svar, scnt = torch.zeros(1, device="cuda"), torch.ones(1, device="cuda"), torch.ones(1, device="cuda")
+    out = torch.zeros(64, 48, device="cuda")     # padded leading dimension, pad columns untouched
+    sout = torch.zeros(1536, device="cuda")
+    for i in range(30):
+        x, y = dev(xs[i]), dev(ys[i])
+        nat.rms_update(x, 64, 45, 45, mean, var, cnt)
+        nat.rms_normalize(x, 64, 45, 45, mean, var, 1e-8, out, 48)
+        nat.rms_update(y, 1536, 1, 1, smean, svar, scnt)
+        nat.rms_normalize(y, 1536, 1, 1, smean, svar, 1e-8, sout, 1)
+        torch.cuda.synchronize()
+        st = np.concatenate([mean.cpu().numpy(), var.cpu().numpy(), cnt.cpu().numpy()])
+        np.testing.assert_allclose(st, g["vec_state"][i], rtol=2e-6, atol=1e-6)
+        np.testing.assert_allclose([float(smean), float(svar), float(scnt)], g["sca_state"][i], rtol=2e-6, atol=1e-6)
+        if i == 0:
+            np.testing.assert_allclose(out.cpu().numpy()[:, :45], g["vec_out_first"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(out.cpu().numpy()[:, :45], g["vec_out_last"], rtol=1e-5, atol=1e-5)
+    assert float(out[:, 45:].abs().max()) == 0.0
+    np.testing.assert_allclose(sout.cpu().numpy()[:64], g["sca_out_last"], rtol=1e-5, atol=1e-5)
+    # two-phase form (all-reduce point between moments and merge) gives the same state
+    m2, v2, c2 = torch.zeros(45, device="cuda"), torch.ones(45, device="cuda"), torch.ones(1, device="cuda")
+    sums = torch.zeros(90, device="cuda", dtype=torch.float64)
+    for i in range(30):
+        nat.rms_moments(dev(xs[i]), 64, 45, 45, sums)
+        nat.rms_merge(sums, 64, 45, m2, v2, c2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(m2.cpu().numpy(), mean.cpu().numpy())
+    np.testing.assert_array_equal(v2.cpu().numpy(), var.cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------- MLP
+def flat_params(native, shape, lay, sd, device="cuda"):
+    """reference state_dict (numpy) -> padded flat fp32 buffer in the library's layout"""
+    flat = np.zeros(lay.n_flat, np.float32)
+    A = shape.act_dim
+    flat[lay.off_logstd:lay.off_logstd + A] = sd["actor_logstd"].reshape(-1)
+    for net, pre in ((0, "critic"), (1, "actor_mean")):
+        for l in range(shape.n_hidden + 1):
+            w, b = sd[f"{pre}.{2 * l}.weight"], sd[f"{pre}.{2 * l}.bias"]
+            out, inp = w.shape
+            ld = lay.in_dim[l]
+            view = flat[lay.off_w[net][l]:lay.off_w[net][l] + out * ld].reshape(out, ld)
+            view[:, :inp] = w
+            flat[lay.off_b[net][l]:lay.off_b[net][l] + out] = b
+    return torch.from_numpy(flat).to(device)
+
+
+def unflatten_grad(shape, lay, flat, sd_like):
+    out = {"actor_logstd": flat[lay.off_logstd:lay.off_logstd + shape.act_dim].reshape(1, -1)}
+    for net, pre in ((0, "critic"), (1, "actor_mean")):
+        for l in range(shape.n_hidden + 1):
+            o, i = sd_like[f"{pre}.{2 * l}.weight"].shape
+            ld = lay.in_dim[l]
+            out[f"{pre}.{2 * l}.weight"] = flat[lay.off_w[net][l]:lay.off_w[net][l] + o * ld].reshape(o, ld)[:, :i]
+            out[f"{pre}.{2 * l}.bias"] = flat[lay.off_b[net][l]:lay.off_b[net][l] + o]
+    return out
+
+
+@pytest.mark.parametrize("D,A,hidden,B", [(45, 12, (512, 256, 128), 96), (48, 12, (256, 256, 256), 4096),
+                                           (45, 12, (512, 256, 128), 1000)])
+def test_policy_act_vs_oracle_and_golden(nat, golden, D, A, hidden, B):
+    from cat_envs import native
+    shape = native.shape_of(D, A, hidden)
+    lay = native.layout_of(shape)
+    w = S.agent_weights(3, D, A, hidden)
+    ag = PO.AgentOracle(D, A, hidden)
+    ag.load(w)
+    params = flat_params(native, shape, lay, w)
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal((B, D)).astype(np.float32)
+    eps = rs.standard_normal((B, A)).astype(np.float32)
+    xp = np.zeros((B, lay.obs_pad), np.float32)
+    xp[:, :D] = x
+    act, logp, val = torch.empty(B, A, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    nat.mlp_reserve(shape, B)
+    nat.policy_act(shape, params, dev(xp), B, dev(eps), act, logp, val)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        a, lp, _, v = ag.get_action_and_value(torch.from_numpy(x), eps=torch.from_numpy(eps))
+    tol = dict(rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(act.cpu().numpy(), a.numpy(), **tol)
+    np.testing.assert_allclose(val.cpu().numpy(), v.numpy()[:, 0], **tol)
+    np.testing.assert_allclose(logp.cpu().numpy(), lp.numpy(), rtol=1e-5, atol=1e-4)
+    val2 = torch.empty(B, device="cuda")
+    nat.value(shape, params, dev(xp), B, val2)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(val2.cpu().numpy(), val.cpu().numpy())
+    if hidden == (512, 256, 128) and B == 96:
+        g = golden("agent")      # the reference Agent itself on these weights / inputs
+        np.testing.assert_allclose(act.cpu().numpy(), g["action"], **tol)
+        np.testing.assert_allclose(logp.cpu().numpy(), g["logprob"], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(val.cpu().numpy(), g["value"][:, 0], **tol)
+        # deterministic path: eps = NULL -> action = mean
+        nat.policy_act(shape, params, dev(xp), B, None, act, logp, val)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            am, _, _, _ = ag.get_action_and_value(torch.from_numpy(x), deterministic=True)
+        np.testing.assert_allclose(act.cpu().numpy(), am.numpy(), **tol)
+
+
+def _minibatch_case(D, A, hidden, Bsz, M, seed):
+    rs = np.random.RandomState(seed)
+    return dict(
+        obs=rs.standard_normal((Bsz, D)).astype(np.float32),
+        act=rs.standard_normal((Bsz, A)).astype(np.float32) * 0.7,
+        logp=(rs.standard_normal(Bsz) * 0.5 - 12.0).astype(np.float32),
+        adv=rs.standard_normal(Bsz).astype(np.float32) * 2 + 0.3,
+        ret=rs.standard_normal(Bsz).astype(np.float32),
+        val=rs.standard_normal(Bsz).astype(np.float32),
+        inds=rs.permutation(Bsz)[:M].astype(np.int64),
+        vmean=np.float32(0.37), vvar=np.float32(2.3))
+
+
+@pytest.mark.parametrize("D,A,hidden,Bsz,M,flags", [
+    (45, 12, (512, 256, 128), 1536, 512, (True, True)),
+    (45, 12, (512, 256, 128), 1536, 500, (False, False)),     # ragged minibatch, no adv-norm / no v-clip
+    (48, 12, (256, 256, 256), 8192, 4096, (True, True)),
+    (45, 12, (512, 256, 128), 98304, 16384, (True, True)),    # the reference's full minibatch
+])
+def test_ppo_minibatch_grad_vs_autograd_oracle(nat, D, A, hidden, Bsz, M, flags):
+    from cat_envs import native
+    norm_adv, clip_vloss = flags
+    shape = native.shape_of(D, A, hidden)
+    lay = native.layout_of(shape)
+    w = S.agent_weights(5, D, A, hidden)
+    c = _minibatch_case(D, A, hidden, Bsz, M, 6)
+    # make log-probs realistic so that ratios straddle the clip range: old logp = new logp + noise
+    ag = PO.AgentOracle(D, A, hidden)
+    ag.load(w)
+    ag.value_rms.mean, ag.value_rms.var = torch.tensor(float(c["vmean"])), torch.tensor(float(c["vvar"]))
+    with torch.no_grad():
+        _, lp0, _, _ = ag.get_action_and_value(torch.from_numpy(c["obs"]), torch.from_numpy(c["act"]))
+    rs = np.random.RandomState(7)
+    c["logp"] = (lp0.numpy() + rs.standard_normal(Bsz).astype(np.float32) * 0.25).astype(np.float32)
+    cfg = dict(clip_coef=0.2, ent_coef=0.001, vf_coef=2.0, norm_adv=norm_adv, clip_vloss=clip_vloss)
+    params_t = [p.requires_grad_(True) for p in ag.parameters()]
+    mb = torch.from_numpy(c["inds"])
+    loss, st = PO.ppo_minibatch_loss(ag, torch.from_numpy(c["obs"])[mb], torch.from_numpy(c["act"])[mb],
+                                     torch.from_numpy(c["logp"])[mb], torch.from_numpy(c["adv"])[mb],
+                                     torch.from_numpy(c["ret"])[mb], torch.from_numpy(c["val"])[mb], cfg)
+    loss.backward()
+    ref_grad = {k: v.grad.numpy() for k, v in ag.p.items()}
+
+    params = flat_params(native, shape, lay, w)
+    obs_p = np.zeros((Bsz, lay.obs_pad), np.float32)
+    obs_p[:, :D] = c["obs"]
+    grad = torch.full((lay.n_flat,), 7.0, device="cuda")
+    grad_pad_probe = grad.clone()
+    diag = torch.zeros(8, device="cuda")
+    hp = native.PpoHparams(0.2, 0.001, 2.0, int(norm_adv), int(clip_vloss), 1.0 / M, 0)
+    nat.mlp_reserve(shape, M)
+    args = (shape, hp, params, dev(obs_p), dev(c["act"]), dev(c["logp"]), dev(c["adv"]), dev(c["ret"]),
+            dev(c["val"]), dev(c["inds"]), dev(np.array([c["vmean"]])), dev(np.array([c["vvar"]])), None, grad, diag)
+    nat.ppo_minibatch_grad(*args)
+    torch.cuda.synchronize()
+    d = diag.cpu().numpy()
+    exp = [float(st["pg_loss"]), float(st["v_loss"]), float(st["entropy"]), float(st["loss"]),
+           float(st["approx_kl"]), float(st["old_approx_kl"]), float(st["clipfrac"])]
+    np.testing.assert_allclose(d[:7], exp, rtol=2e-4, atol=2e-6)
+    assert d[7] == 1.0
+    got = unflatten_grad(shape, lay, grad.cpu().numpy(), w)
+    gnorm = math.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ref_grad.values()))
+    for k, v in ref_grad.items():
+        # <= 1e-4 relative (GEMM reassociation); scale by the tensor's own magnitude
+        scale = max(np.abs(v).max(), 1e-8)
+        err = np.abs(got[k].reshape(v.shape) - v).max() / scale
+        assert err < 2e-4, (k, err)
+    gnorm_got = math.sqrt(sum(float((got[k].astype(np.float64) ** 2).sum()) for k in ref_grad))
+    assert abs(gnorm_got - gnorm) < 1e-4 * gnorm
+    # determinism (no float atomics): a second run is bit-identical
+    grad2, diag2 = torch.zeros_like(grad), torch.zeros(8, device="cuda")
+    nat.ppo_minibatch_grad(*args[:-2], grad2, diag2)
+    torch.cuda.synchronize()
+    written = grad.cpu().numpy() != grad_pad_probe.cpu().numpy()
+    np.testing.assert_array_equal(grad.cpu().numpy()[written], grad2.cpu().numpy()[written])
+
+
+def test_clip_adam_vs_torch(nat):
+    n = 377_300
+    rs = np.random.RandomState(8)
+    p0 = rs.standard_normal(n).astype(np.float32)
+    p_ref = torch.from_numpy(p0.copy()).requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=3e-4, eps=1e-5)
+    p, m, v = dev(p0), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 6):
+        scale = 10.0 if step % 2 else 0.001      # exercise both clip branches
+        g0 = (rs.standard_normal(n) * scale / math.sqrt(n)).astype(np.float32)
+        lr = 3e-4 * (1 - (step - 1) / 10)
+        opt.param_groups[0]["lr"] = lr
+        p_ref.grad = torch.from_numpy(g0.copy())
+        torch.nn.utils.clip_grad_norm_([p_ref], 1.0)
+        opt.step()
+        g = dev(g0)
+        nat.clip_adam(p, g, m, v, n, 1.0, lr, 0.9, 0.999, 1e-5, step)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(g.cpu().numpy(), p_ref.grad.numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(p.cpu().numpy(), p_ref.detach().numpy(), rtol=1e-6, atol=1e-6)
+    st = opt.state[p_ref]
+    np.testing.assert_allclose(m.cpu().numpy(), st["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(v.cpu().numpy(), st["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_errors_are_loud(nat):
+    from cat_envs import native
+    with pytest.raises(ValueError):
+        native.layout_of(native.shape_of(45, 12, (100, 64)))
+    shape = native.shape_of(45, 12, (512, 256, 128))
+    lay = native.layout_of(shape)
+    assert lay.n_params == 377241 and lay.obs_pad == 48
+    fresh = native.Native()
+    params = torch.zeros(lay.n_flat, device="cuda")
+    x = torch.zeros(1 << 20, 48, device="cuda")
+    a, l, v = torch.zeros(1 << 20, 12, device="cuda"), torch.zeros(1 << 20, device="cuda"), torch.zeros(1 << 20, device="cuda")
+    with pytest.raises(RuntimeError, match="workspace"):
+        fresh.policy_act(shape, params, x, 1 << 20, None, a, l, v)     # default workspace too small
+    with pytest.raises(RuntimeError):
+        fresh.gae(a[:, 0].contiguous().view(1, -1), v.view(1, -1), v.view(1, -1), v.view(1, -1), v, v, v, 0.99, 0.95,
+                  torch.zeros(1, 1 << 20), torch.zeros(1, 1 << 20, device="cuda"))  # CPU tensor rejected
