@@ -1,0 +1,225 @@
+"""bench.py - env-steps/s of the CaT-PPO hot path on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full CaT-PPO iteration (BASELINE.json metric): T x [obs normaliser
+update+apply, policy/value forward + sample, constraint-term evaluation + CaT step + reward /
+dones epilogue, rollout-buffer writes] + bootstrap value + GAE + value normaliser x2 +
+E epochs x ceil(N*T/M) minibatch steps (gather, forward, losses, backward, [RCCL gradient
+all-reduce], global-norm clip, Adam).  Synthetic streams are generated before the timed region
+and are device resident.  Workload (default) = BASELINE.json configs[1]: 4096 envs x 24, Solo12,
+6 constraint terms (42 columns), 48-d obs, 3x256 MLP;  --workload reference runs the reference's
+own shapes (45-d obs, 13 terms / 78 columns, 512/256/128 MLPs).  Weak scaling: every rank owns
+4096 envs and a 16384-sample minibatch share (global minibatch = 16384 x N).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "constraints-as-terminations_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(num_envs=4096, num_steps=24, obs_dim=48, hidden=(256, 256, 256), six_terms=True,
+                 desc="4096 envs x 24, Solo12 48-d obs, 6 ConstraintTerms (42 cols), 3x256 MLP, 5 epochs x 6 minibatches of 16384"),
+    # the reference's real shapes
+    "reference": dict(num_envs=4096, num_steps=24, obs_dim=45, hidden=(512, 256, 128), six_terms=False,
+                      desc="4096 envs x 24, Solo12 45-d obs, 13 ConstraintTerms (78 cols), 512/256/128 MLPs, 5 epochs x 6 minibatches of 16384"),
+}
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+def fwd_macs(obs_dim, hidden, act_dim=12):
+    dims = [obs_dim, *hidden]
+    body = sum(i * o for i, o in zip(dims[:-1], dims[1:]))
+    return 2 * body + hidden[-1] * (act_dim + 1)
+
+
+def build(workload, seed, device_index):
+    import smoke_impl
+    from cat_envs.shim import make
+    from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+    w = WORKLOADS[workload]
+    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(w["num_envs"], w["num_steps"], 16384, 5, 2000, w["hidden"],
+                                                    w["six_terms"], obs_dim=w["obs_dim"], stream_steps=48, seed=seed)
+    env_cfg.sim.device = f"cuda:{device_index}"
+    env = make(task, cfg=env_cfg)
+    trainer = PPOTrainer(env, agent_cfg)
+    return env, trainer, agent_cfg
+
+
+def pick_cpu_threads(obs_dim, hidden):
+    """torch-CPU thread count with the best throughput on this host for the dominant op (an MLP
+    forward/backward on 16384 rows); one thread per core is far from optimal on a 256-core host."""
+    import torch.nn as nn
+    dims = [obs_dim, *hidden]
+    net = nn.Sequential(*[m for i, o in zip(dims[:-1], dims[1:]) for m in (nn.Linear(i, o), nn.ELU())])
+    x = torch.randn(16384, obs_dim)
+    best, best_t = 1, float("inf")
+    for n in (8, 16, 32, 64, 128):
+        if n > (os.cpu_count() or 1):
+            break
+        torch.set_num_threads(n)
+        net(x).sum().backward()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            net(x).sum().backward()
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = n, dt
+    return best
+
+
+def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=25.0):
+    """the oracle (torch-CPU restatement of PPO() + numpy CaT) timed on the host cores, rank 0 / N=1 only,
+    on a bounded sample of the same workload"""
+    from oracle import env_oracle, ppo_oracle
+    w = WORKLOADS[workload]
+    cores = pick_cpu_threads(trainer.D, w["hidden"])
+    torch.set_num_threads(cores)
+    cpu_env = env_oracle.from_device_env(env)
+    ag = ppo_oracle.AgentOracle(trainer.D, trainer.A, w["hidden"], seed=0)
+    cfg = {k: getattr(agent_cfg, k) for k in ppo_oracle.PPOOracle.DEFAULT_CFG}
+    # bounded sample: ONE epoch of the update instead of five (the update is ~95% of the time and
+    # linear in the epoch count), then scaled back to the full iteration
+    cfg["updates_epochs"] = 1
+    orc = ppo_oracle.PPOOracle(cpu_env, w["num_envs"], trainer.D, trainer.A, cfg=cfg, hidden=w["hidden"], agent=ag)
+    t0 = time.perf_counter()
+    orc.run_iteration()
+    dt = time.perf_counter() - t0
+    tm = orc.timers
+    full = tm["rollout"] + tm["gae"] + 5.0 * tm["update"]
+    steps = w["num_envs"] * w["num_steps"]
+    return {"value": steps / full, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 iteration of {w['num_envs']}x{w['num_steps']} with 1 of 5 update epochs timed "
+                      f"({dt:.1f} s wall), update time scaled x5",
+            "phase_ms": {"rollout_fwd_and_env": 1e3 * tm["rollout"], "cat_env_step": 1e3 * tm["env"],
+                         "gae": 1e3 * tm["gae"], "update_5_epochs": 5e3 * tm["update"]}}
+
+
+def gae_roofline(nat, T, N, reps=50):
+    dev = "cuda"
+    x = [torch.rand(T, N, device=dev) for _ in range(4)]
+    nv, nd, ntd = (torch.rand(N, device=dev) for _ in range(3))
+    adv, ret = torch.empty(T, N, device=dev), torch.empty(T, N, device=dev)
+    f = lambda: nat.gae(x[0], x[1], x[2], x[3], nv, nd, ntd, 0.99, 0.95, adv, ret)
+    for _ in range(5):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    byt = 24.0 * T * N + 12.0 * N
+    return {"T": T, "N": N, "us": us, "GBps": byt / us / 1e3, "frac": byt / us / 1e3 / HBM_PEAK_GBPS}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=42)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+    else:
+        torch.cuda.set_device(0)
+    if a.gpus != world and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
+
+    w = WORKLOADS[a.workload]
+    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local)
+    nat = trainer.nat
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.run_iteration(log=False)
+
+    # ---- timed region: exactly K iterations between barrier + synchronize
+    # HIP events bracket every catppo_ppo_minibatch_grad call (the dominant kernel group) on the stream
+    # it is enqueued on (torch's current stream)
+    ev = []
+    orig = nat.ppo_minibatch_grad
+
+    def timed_grad(*args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(*args, **kw)
+        e1.record()
+        ev.append((e0, e1))
+    nat.ppo_minibatch_grad = timed_grad
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.run_iteration(log=False)
+    barrier()
+    dt = time.perf_counter() - t0
+    nat.ppo_minibatch_grad = orig
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    steps_total = w["num_envs"] * w["num_steps"] * world * a.steps
+    value = steps_total / dt
+
+    if rank == 0:
+        grad_us = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
+        macs = fwd_macs(w["obs_dim"], w["hidden"])
+        M = 16384
+        flops_per_launch = 3 * 2 * macs * M                       # fwd + bwd = 3x fwd, per minibatch
+        ach = flops_per_launch / grad_us / 1e6
+        out = {
+            "metric": "env-steps/s CaT-PPO iteration (rollout + GAE + PPO update)", "value": value,
+            "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": w["num_envs"], "horizon": w["num_steps"],
+                       "global_minibatch": M * world, "parallelism": f"env-sharded dp{world}, RCCL all-reduce of the flat gradient"},
+            "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad (gather, 2x3 grouped fp32-MFMA GEMM launches fwd, "
+                         "head+loss, split-K dW + dX GEMMs, partial reductions) per 16384-sample minibatch",
+                         "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                         "traffic": None, "avg_launch_us": grad_us, "flops_per_launch": flops_per_launch},
+            "gae": {"config_size": gae_roofline(nat, w["num_steps"], w["num_envs"]),
+                    "hbm_sweep": [gae_roofline(nat, 24, 1 << 20, 20), gae_roofline(nat, 48, 1 << 22, 10)],
+                    "bound": "hbm", "peak_GBps": HBM_PEAK_GBPS, "bytes_per_env_step": 24},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload, trainer, env, agent_cfg)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

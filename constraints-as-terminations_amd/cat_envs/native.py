@@ -60,7 +60,9 @@ _SIGNATURES = {
     "catppo_cat_colmax": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "catppo_cat_apply": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "catppo_cat_terms": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "catppo_cat_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "catppo_cat_terms": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32,
+                                   _vp]),
     "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
     "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rms_merge": (C.c_int, [_vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
@@ -68,7 +70,7 @@ _SIGNATURES = {
     "catppo_rms_normalize": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _f32, _vp, _i64, _vp]),
     "catppo_mlp_layout_of": (C.c_int, [C.POINTER(MlpShape), C.POINTER(MlpLayout)]),
     "catppo_mlp_workspace_bytes": (C.c_uint64, [C.POINTER(MlpShape), _i64]),
-    "catppo_policy_act": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_policy_act": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catppo_value": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp]),
     "catppo_ppo_minibatch_grad": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -77,6 +79,17 @@ _SIGNATURES = {
 
 EXPORTS = tuple(_SIGNATURES)
 _lib = None
+_contexts: dict = {}
+
+
+def get(device=None) -> "Native":
+    """process-wide context per HIP device (the manager, the env and PPO share one workspace and
+    therefore one stream order)"""
+    import torch as _t
+    idx = _t.cuda.current_device() if device is None or _t.device(device).index is None else _t.device(device).index
+    if idx not in _contexts:
+        _contexts[idx] = Native(_t.device("cuda", idx))
+    return _contexts[idx]
 
 
 def load_library(path: Optional[str] = None):
@@ -116,7 +129,7 @@ def layout_of(shape: MlpShape) -> MlpLayout:
     if rc != 0:
         raise ValueError(f"unsupported MLP shape (obs={shape.obs_dim}, act={shape.act_dim}, "
                          f"hidden={list(shape.hidden)[:shape.n_hidden]}): hidden widths must be multiples of 64, "
-                         "the last one in {64,128,256,512}, act_dim <= 16")
+                         "the last one in {64,128,256,512}, act_dim <= 15")
     return lay
 
 
@@ -201,9 +214,18 @@ class Native:
             self._stream()))
 
     def cat_terms(self, descs, n_envs, forces, H, B, command, cstr):
-        arr = (TermDesc * len(descs))(*descs)
-        self._ok(self.lib.catppo_cat_terms(self.h, arr, len(descs), int(n_envs), _p(forces), int(H), int(B),
-                                           _p(command), _p(cstr), cstr.shape[1], self._stream()))
+        """forces: (N,H,B,3) view whose env stride may exceed H*B*3; command: (N,3) view with any row stride"""
+        arr = descs if isinstance(descs, C.Array) else (TermDesc * len(descs))(*descs)
+        fstride = forces.stride(0) if forces is not None else 0
+        cld = command.stride(0) if command is not None else 0
+        self._ok(self.lib.catppo_cat_terms(self.h, arr, len(arr), int(n_envs), _p(forces), fstride, int(H), int(B),
+                                           _p(command), cld, _p(cstr), cstr.shape[1], self._stream()))
+
+    def cat_reset(self, ep_viol, ep_prob, episode_length, mask, out):
+        n_terms, N = ep_viol.shape
+        _chk(episode_length, torch.int64, "episode_length")
+        self._ok(self.lib.catppo_cat_reset(self.h, _p(ep_viol), _p(ep_prob), _p(episode_length), _p(mask), n_terms,
+                                           N, _p(out), self._stream()))
 
     # ------------------------------------------------------------------ GAE
     def gae(self, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gae_lambda,
@@ -238,9 +260,9 @@ class Native:
     def mlp_reserve(self, shape: MlpShape, rows: int):
         self.reserve(self.lib.catppo_mlp_workspace_bytes(C.byref(shape), int(rows)))
 
-    def policy_act(self, shape, params, x, n_rows, eps, action, logprob, value):
+    def policy_act(self, shape, params, x, n_rows, eps, action, logprob, value, given_action=None):
         self._ok(self.lib.catppo_policy_act(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
-                                            _p(action), _p(logprob), _p(value), self._stream()))
+                                            _p(given_action), _p(action), _p(logprob), _p(value), self._stream()))
 
     def value(self, shape, params, x, n_rows, value):
         self._ok(self.lib.catppo_value(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(value),

@@ -1,0 +1,278 @@
+"""CaT environment: manager-based RL env whose ``step`` returns the constraint termination
+probability as float ``dones`` and scales the reward by ``(1 - p)``.
+
+Reference: cat/cat_env.py.  Only lines 92-121 and 147 of the reference ``step`` are on the hot
+path (counters, terminations, ``constraint_manager.compute()``, reward scaling, float dones,
+hard resets, manager resets, return tuple); the physics loop (:61-88) is Isaac Sim / PhysX,
+which cannot run on AMD GPUs and is out of scope.  This class therefore drives the same
+managers from a *synthetic simulator*: seeded, device-resident, pre-generated streams of Solo12
+sim state (joint state, gravity, commands, contact forces, air times), rewards, hard resets
+and observations.  One ``copy_`` per step moves the current slab of the stream into
+persistent state buffers (what a simulator's ``scene.update`` does); every manager reads
+views of those buffers, exactly like IsaacLab's ``scene[...]`` data objects.
+
+No host synchronisation happens inside ``step``: resets are handled with masks
+(``exact_reset_sync=True`` restores the reference's ``nonzero()``-based control flow).
+"""
+from __future__ import annotations
+
+import math
+import types
+from collections.abc import Sequence
+
+import torch
+
+from cat_envs.shim import SceneEntityCfg  # noqa: F401  (re-export for term configs)
+
+from .constraint_manager import ConstraintManager
+
+SOLO12_JOINTS = ["FL_HAA", "FL_HFE", "FL_KFE", "FR_HAA", "FR_HFE", "FR_KFE",
+                 "HL_HAA", "HL_HFE", "HL_KFE", "HR_HAA", "HR_HFE", "HR_KFE"]
+SOLO12_BODIES = ["base_link"] + [f"{leg}_{part}" for leg in ("FL", "FR", "HL", "HR")
+                                 for part in ("SHOULDER", "UPPER_LEG", "LOWER_LEG", "FOOT")]
+DEFAULT_JOINT_POS = [0.05, 0.4, -0.8, -0.05, 0.4, -0.8, 0.05, 0.4, -0.8, -0.05, 0.4, -0.8]
+
+
+class _Space:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class SyntheticSolo12Sim:
+    """Pre-generated sim-state streams (SURVEY 8d distributions), resident in HBM.
+
+    Packed layout per env and step (floats): joint_pos 12 | joint_vel 12 | joint_acc 12 |
+    applied_torque 12 | projected_gravity_b 3 | root_pos_w 3 | command 3 | last_air_time B |
+    first_contact B | net_forces_w_history H*B*3 | reward 1 | hard_reset 1 | obs D.
+    """
+
+    H = 3
+
+    def __init__(self, num_envs: int, obs_dim: int, device, seed: int, stream_steps: int):
+        self.N, self.D, self.device, self.S = num_envs, obs_dim, torch.device(device), stream_steps
+        J, B, H = len(SOLO12_JOINTS), len(SOLO12_BODIES), self.H
+        self.J, self.B = J, B
+        fields = [("joint_pos", J), ("joint_vel", J), ("joint_acc", J), ("applied_torque", J),
+                  ("projected_gravity_b", 3), ("root_pos_w", 3), ("command", 3), ("last_air_time", B),
+                  ("first_contact", B), ("forces", H * B * 3), ("reward", 1), ("hard_reset", 1), ("obs", obs_dim)]
+        self.off, o = {}, 0
+        for name, w in fields:
+            self.off[name] = (o, w)
+            o += w
+        self.F = (o + 3) // 4 * 4
+        g = torch.Generator(device=self.device)
+        g.manual_seed(int(seed))
+        N, S, F = num_envs, stream_steps, self.F
+        st = torch.zeros(S, N, F, device=self.device)
+
+        def put(name, value):
+            a, w = self.off[name]
+            st[:, :, a:a + w] = value.reshape(S, N, w)
+
+        def randn(*shape):
+            return torch.randn(*shape, device=self.device, generator=g)
+
+        def rand(*shape):
+            return torch.rand(*shape, device=self.device, generator=g)
+
+        dq = torch.tensor(DEFAULT_JOINT_POS, device=self.device)
+        put("joint_pos", dq + randn(S, N, J) * 0.5)
+        put("joint_vel", randn(S, N, J) * 8.0)
+        put("joint_acc", randn(S, N, J) * 400.0)
+        put("applied_torque", randn(S, N, J) * 2.0)
+        grav = torch.cat([randn(S, N, 2) * 0.12, -torch.ones(S, N, 1, device=self.device)], -1)
+        grav[..., 2] = torch.where(rand(S, N) < 0.003, 1.0, -1.0)      # rare roll-over
+        put("projected_gravity_b", grav / grav.norm(dim=-1, keepdim=True))
+        put("root_pos_w", torch.cat([randn(S, N, 2), 0.25 + randn(S, N, 1) * 0.03], -1))
+        lo = torch.tensor([-0.3, -0.7, -0.78], device=self.device)
+        hi = torch.tensor([1.0, 0.7, 0.78], device=self.device)
+        cmd = lo + rand(S, N, 3) * (hi - lo)
+        cmd = cmd * (cmd.norm(dim=-1, keepdim=True) > 0.1)              # dead-zone like the reference commands
+        cmd = cmd * (rand(S, N, 1) > 0.02)                              # rel_standing_envs = 0.02
+        put("command", cmd)
+        put("last_air_time", rand(S, N, B) * 0.5)
+        put("first_contact", (rand(S, N, B) < 0.1).float())
+        is_foot = torch.tensor([n.endswith("_FOOT") for n in SOLO12_BODIES], device=self.device)
+        p_contact = torch.where(is_foot, 0.5, 0.002)
+        forces = randn(S, N, H, B, 3).abs() * 20.0 * (rand(S, N, H, B, 1) < p_contact.view(1, 1, 1, B, 1))
+        put("forces", forces)
+        put("reward", rand(S, N, 1) * 1.5)
+        put("hard_reset", (rand(S, N, 1) < 0.01).float())
+        put("obs", randn(S, N, obs_dim))
+        self.stream = st
+        self.cur = torch.zeros(N, F, device=self.device)       # persistent "simulator state" buffers
+        self.cursor = -1
+        self.default_joint_pos = dq.repeat(N, 1).contiguous()
+        self._build_scene()
+
+    def view(self, name):
+        a, w = self.off[name]
+        return self.cur[:, a:a + w]
+
+    def _build_scene(self):
+        N, H, B = self.N, self.H, self.B
+        a, w = self.off["forces"]
+        forces = self.cur.as_strided((N, H, B, 3), (self.F, B * 3, 3, 1), self.cur.storage_offset() + a)
+        robot = types.SimpleNamespace(
+            joint_names=list(SOLO12_JOINTS), body_names=list(SOLO12_BODIES),
+            data=types.SimpleNamespace(
+                joint_pos=self.view("joint_pos"), default_joint_pos=self.default_joint_pos,
+                joint_vel=self.view("joint_vel"), joint_acc=self.view("joint_acc"),
+                applied_torque=self.view("applied_torque"), projected_gravity_b=self.view("projected_gravity_b"),
+                root_pos_w=self.view("root_pos_w")))
+        fc = self.view("first_contact")
+        sensor = types.SimpleNamespace(
+            joint_names=[], body_names=list(SOLO12_BODIES),
+            data=types.SimpleNamespace(net_forces_w_history=forces, last_air_time=self.view("last_air_time")),
+            first_contact_f32=fc, compute_first_contact=lambda dt: fc > 0.5)
+        self.scene = {"robot": robot, "contact_forces": sensor}
+
+    def step(self):
+        self.cursor = (self.cursor + 1) % self.S
+        self.cur.copy_(self.stream[self.cursor])               # "scene.update": one contiguous slab
+
+
+class _ActionManager:
+    def __init__(self, n, a, device):
+        self._action = torch.zeros(n, a, device=device)
+        self._prev_action = torch.zeros(n, a, device=device)
+        self.total_action_dim = a
+
+    def process_action(self, action):
+        self._prev_action.copy_(self._action)
+        self._action.copy_(action)
+
+    def reset(self, env_ids=None):
+        return {}
+
+
+class _CurriculumManager:
+    def __init__(self, cfg, env):
+        self._env = env
+        items = cfg.items() if isinstance(cfg, dict) else (cfg.__dict__.items() if cfg is not None else [])
+        self._terms = [(n, t) for n, t in items if t is not None]
+        self._state = {}
+
+    def compute(self, env_ids=None):
+        for name, term in self._terms:
+            self._state[name] = term.func(self._env, env_ids, **term.params)
+
+    def reset(self, env_ids=None):
+        return {f"Curriculum/{n}": v for n, v in self._state.items() if isinstance(v, (int, float))}
+
+
+class CaTEnv:
+    """Drop-in for the reference ``CaTEnv`` on the path PPO consumes (``unwrapped.num_envs``,
+    ``single_observation_space["policy"]``, ``single_action_space``, ``reset()``, ``step()``)."""
+
+    persistent_state_buffers = True      # term descriptors may cache raw pointers
+
+    def __init__(self, cfg, render_mode: str | None = None, **kwargs):
+        self.cfg = cfg
+        self.render_mode = render_mode
+        self.num_envs = int(cfg.scene.num_envs)
+        dev = getattr(cfg.sim, "device", "cuda:0")
+        if not torch.cuda.is_available() or torch.device(dev).type != "cuda":
+            raise RuntimeError("CaTEnv needs a HIP device (MI355X): the constraint manager and the synthetic "
+                               "simulator are device resident; there is no CPU fallback")
+        self.device = torch.device(dev)
+        self.physics_dt = cfg.sim.dt
+        self.step_dt = cfg.sim.dt * cfg.decimation
+        self.max_episode_length_s = cfg.episode_length_s
+        self.max_episode_length = math.ceil(cfg.episode_length_s / self.step_dt)
+        syn = cfg.synthetic
+        self.obs_dim, self.act_dim = int(syn.obs_dim), len(SOLO12_JOINTS)
+        seed = int(getattr(cfg, "seed", 0) or 0)
+        self.sim = SyntheticSolo12Sim(self.num_envs, self.obs_dim, self.device, seed + int(syn.seed_offset),
+                                      int(syn.stream_steps))
+        self.scene = self.sim.scene
+        self.exact_reset_sync = bool(getattr(syn, "exact_reset_sync", False))
+        g = torch.Generator(device=self.device)
+        g.manual_seed(seed + 17)
+        self.episode_length_buf = torch.randint(0, self.max_episode_length, (self.num_envs,), device=self.device,
+                                                generator=g, dtype=torch.long)
+        self.common_step_counter = 0
+        self._sim_step_counter = 0
+        self.extras: dict = {}
+        self.single_observation_space = {"policy": _Space((self.obs_dim,))}
+        self.single_action_space = _Space((self.act_dim,))
+        self.reward_buf = torch.zeros(self.num_envs, device=self.device)
+        self._dones = torch.zeros(self.num_envs, device=self.device)
+        self.reset_buf = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        self.reset_terminated = torch.zeros_like(self.reset_buf)
+        self.reset_time_outs = torch.zeros_like(self.reset_buf)
+        self.obs_buf = {"policy": self.sim.view("obs")}
+        self.load_managers()
+
+    # gym-style plumbing ---------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    def close(self):
+        pass
+
+    def seed(self, seed: int = -1) -> int:
+        return seed
+
+    # managers --------------------------------------------------------------------------------
+    def load_managers(self):
+        """reference: cat_env.py:18-40 (constraint manager created after the base managers)"""
+        self.action_manager = _ActionManager(self.num_envs, self.act_dim, self.device)
+        cmd = self.sim.view("command")
+        self.command_manager = types.SimpleNamespace(get_command=lambda name: cmd, reset=lambda ids=None: {},
+                                                     compute=lambda dt: None)
+        self.curriculum_manager = _CurriculumManager(getattr(self.cfg, "curriculum", None), self)
+        if hasattr(self.cfg, "constraints"):
+            self.constraint_manager = ConstraintManager(self.cfg.constraints, self)
+            print("[INFO] Constraint Manager: ", self.constraint_manager)
+
+    # episode control -------------------------------------------------------------------------
+    def reset(self, seed: int | None = None, options=None):
+        self.sim.step()
+        self.extras = {}
+        return self.obs_buf, self.extras
+
+    def step(self, action: torch.Tensor):
+        """reference: cat_env.py:42-147 with the physics loop replaced by the synthetic stream."""
+        self.action_manager.process_action(action.to(self.device))
+        self._sim_step_counter += self.cfg.decimation
+        self.sim.step()
+        # -- counters (cat_env.py:92-93)
+        self.episode_length_buf += 1
+        self.common_step_counter += 1
+        # -- terminations (:95-97): hard resets come from the stream, time-outs from the counter
+        torch.ge(self.episode_length_buf, self.max_episode_length, out=self.reset_time_outs)
+        torch.gt(self.sim.view("hard_reset")[:, 0], 0.5, out=self.reset_terminated)
+        torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
+        # -- CaT (:99-107,118-121): probability, reward *= (1-p) clipped at 0, dones = p, dones[reset] = 1
+        self.reward_buf.copy_(self.sim.view("reward")[:, 0])          # reward_manager.compute(dt)
+        if hasattr(self.cfg, "constraints"):
+            self.constraint_manager.compute(reward=self.reward_buf, reset_mask=self.reset_buf, dones=self._dones)
+            dones = self._dones
+        else:
+            dones = self.reset_buf.float()
+        # -- resets (:118-125)
+        if self.exact_reset_sync:
+            ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)   # host sync, reference control flow
+            if len(ids) > 0:
+                self._reset_idx(ids)
+        else:
+            self._reset_idx(self.reset_buf)
+        # -- observations (:144)
+        return self.obs_buf, self.reward_buf, dones, self.reset_time_outs, self.extras
+
+    def _reset_idx(self, env_ids: Sequence[int] | torch.Tensor):
+        """reference: cat_env.py:149-200.  ``env_ids`` may be a bool mask (sync-free path)."""
+        self.curriculum_manager.compute(env_ids=env_ids)
+        log = {}
+        log.update(self.action_manager.reset(env_ids))
+        if hasattr(self.cfg, "constraints"):
+            log.update(self.constraint_manager.reset(env_ids))
+            self.extras["log_packed"] = self.constraint_manager.log_packed
+        log.update(self.curriculum_manager.reset(env_ids))
+        self.extras["log"] = log
+        if isinstance(env_ids, torch.Tensor) and env_ids.dtype == torch.bool:
+            self.episode_length_buf.masked_fill_(env_ids, 0)
+        else:
+            self.episode_length_buf[env_ids] = 0

@@ -1,0 +1,344 @@
+"""Constraint manager: per-env constraint violations -> float termination probability.
+
+Same public surface as the reference (cat/constraint_manager.py): ``CaT`` with
+``add/get_probs/get_raw_constraints/get_running_maxes/get_max_p/get_str/log_all/get_names/
+get_vals/reset`` and the dict attributes ``running_maxes/probs/max_p/raw_constraints``;
+``ConstraintManager(cfg, env, tau, min_p)`` with ``compute/reset/active_terms/get_term_cfg/
+set_term_cfg`` raising the same exceptions.
+
+What differs is where the arithmetic runs.  The reference issues ~15 eager launches and a
+host sync per term per env step; here ``ConstraintManager.compute()`` is
+
+    catppo_cat_terms   (all term functions of cat/constraints.py -> cstr[N,K], one launch)
+    catppo_cat_step    (column max, running-max EMA, probabilities, per-env max, per-term
+                        episode statistics, reward scaling, float dones: three launches)
+
+with no host sync.  All terms live side by side in packed (N,K) / (K,) buffers; the per-term
+dict entries the reference exposes are views into them.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Sequence
+from typing import Dict, List
+
+import torch
+
+from cat_envs import native
+from cat_envs.shim import ManagerBase, ManagerTermBase
+
+from .manager_constraint_cfg import ConstraintTermCfg
+
+
+def _as_matrix(constraint: torch.Tensor, device) -> torch.Tensor:
+    """device / float / (N,) -> (N,1) normalisation of constraint_manager.py:42-49"""
+    if constraint.device != device:
+        constraint = constraint.to(device)
+    if not torch.is_floating_point(constraint) or constraint.dtype != torch.float32:
+        constraint = constraint.float()
+    if constraint.ndim == 1:
+        constraint = constraint.unsqueeze(1)
+    return constraint
+
+
+class CaT:
+    """Termination probabilities from constraint violations (reference: constraint_manager.py:22-116)."""
+
+    def __init__(self, tau: float = 0.95, min_p: float = 0.0):
+        self.running_maxes: Dict[str, torch.Tensor] = {}   # (1,C) EMA of the per-column max violation
+        self.probs: Dict[str, torch.Tensor] = {}           # (N,C) termination probabilities
+        self.max_p: Dict[str, torch.Tensor] = {}           # (C,)  maximum termination probability
+        self.raw_constraints: Dict[str, torch.Tensor] = {} # (N,C) raw constraint values
+        self.tau = tau
+        self.min_p = min_p
+        self._device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self._scratch: Dict[str, tuple] = {}
+
+    def reset(self):
+        self.probs.clear()
+        self.raw_constraints.clear()
+
+    # -- one term at a time (the reference's call pattern; the manager uses the packed path below)
+    def add(self, name: str, constraint: torch.Tensor, max_p: float = 0.1):
+        nat = native.get(self._device if self._device.type == "cuda" else None)
+        c = _as_matrix(constraint, nat.device).contiguous()
+        n, width = c.shape
+        first = name not in self.running_maxes
+        if first or self.running_maxes[name].shape[1] != width:
+            self.running_maxes[name] = torch.zeros(1, width, device=nat.device)
+            first = True
+        sc = self._scratch.get(name)
+        if sc is None or sc[0].shape != (n, width):
+            sc = (torch.empty(n, width, device=nat.device), torch.empty(n, device=nat.device),
+                  torch.zeros(1, n, device=nat.device), torch.zeros(1, n, device=nat.device))
+            self._scratch[name] = sc
+        probs, prob_max, viol, eprob = sc
+        off = (C.c_int32 * 2)(0, width)
+        dp = (C.c_float * 1)(native.f32(max_p - self.min_p))
+        nat.cat_step(c, off, dp, self.min_p, self.tau, first, self.running_maxes[name].view(-1), prob_max, viol,
+                     eprob, probs=probs)
+        self.raw_constraints[name] = c
+        self.probs[name] = probs
+        self.max_p[name] = torch.full((width,), max_p, dtype=torch.float, device=nat.device)
+
+    def get_probs(self) -> torch.Tensor:
+        if not self.probs:
+            return torch.tensor([], device=self._device)
+        return torch.cat(list(self.probs.values()), dim=1).max(1).values
+
+    def get_raw_constraints(self) -> torch.Tensor:
+        return (torch.cat(list(self.raw_constraints.values()), dim=1) if self.raw_constraints
+                else torch.tensor([], device=self._device))
+
+    def get_running_maxes(self) -> torch.Tensor:
+        return (torch.cat(list(self.running_maxes.values()), dim=1) if self.running_maxes
+                else torch.tensor([], device=self._device))
+
+    def get_max_p(self) -> torch.Tensor:
+        return torch.cat(list(self.max_p.values())) if self.max_p else torch.tensor([], device=self._device)
+
+    def get_str(self, names: List[str] | None = None) -> str:
+        names = names or list(self.probs.keys())
+        return " ".join(f"{n}: {100.0 * self.probs[n].max(1).values.gt(0.0).float().mean().item():.1f}"
+                        for n in names)
+
+    def log_all(self, episode_sums: Dict[str, torch.Tensor]):
+        for name, probs in self.probs.items():
+            key = f"cstr_{name}"
+            values = probs.max(1).values.gt(0.0).float()
+            if key not in episode_sums:
+                episode_sums[key] = torch.zeros_like(values)
+            episode_sums[key].add_(values)
+
+    def get_names(self) -> List[str]:
+        return list(self.probs.keys())
+
+    def get_vals(self) -> List[float]:
+        return [100.0 * p.max(1).values.gt(0.0).float().mean().item() for p in self.probs.values()]
+
+    # -- packed storage shared with ConstraintManager ------------------------------------------
+    def _bind_packed(self, names, widths, n_envs: int, device):
+        K = sum(widths)
+        self._p_cstr = torch.zeros(n_envs, K, device=device)
+        self._p_probs = torch.zeros(n_envs, K, device=device)
+        self._p_rm = torch.zeros(K, device=device)
+        self._p_first = True
+        off = 0
+        for n, w in zip(names, widths):
+            self.raw_constraints[n] = self._p_cstr[:, off:off + w]
+            self.probs[n] = self._p_probs[:, off:off + w]
+            self.running_maxes[n] = self._p_rm[off:off + w].unsqueeze(0)
+            off += w
+
+
+class ConstraintManager(ManagerBase):
+    """Manager of constraint terms (reference: constraint_manager.py:119-265)."""
+
+    LOG_RING = 128  # reset() results stay valid for this many subsequent resets
+
+    def __init__(self, cfg: object, env, tau: float = 0.95, min_p: float = 0.0):
+        self.cat = CaT(tau, min_p)
+        self._device = torch.device(env.device)
+        self._term_names: List[str] = []
+        self._term_cfgs: List[ConstraintTermCfg] = []
+        self._class_term_cfgs: List[ConstraintTermCfg] = []
+        super().__init__(cfg, env)          # -> _prepare_terms()
+
+        n, nt = self.num_envs, len(self._term_names)
+        # packed per-term statistics; the reference's per-name dicts are row views
+        self._ep_viol = torch.zeros(max(nt, 1), n, dtype=torch.float, device=self._device)
+        self._ep_prob = torch.zeros(max(nt, 1), n, dtype=torch.float, device=self._device)
+        self._episode_sums = {name: self._ep_viol[i] for i, name in enumerate(self._term_names)}
+        self._cstr_mean_values = {name: self._ep_prob[i] for i, name in enumerate(self._term_names)}
+        self._cstr_prob_buf = torch.zeros(n, dtype=torch.float, device=self._device)
+        self._log_ring = torch.zeros(self.LOG_RING, 2 * max(nt, 1), device=self._device)
+        self._log_views = None
+        self._log_pos = 0
+        self._bound = False
+        self._fused = False
+        self._widths: List[int] = []
+        self._term_off = None
+        #: optional torch.distributed process group: envs are sharded over its ranks and the column
+        #: maxima are MAX-all-reduced so every shard sees the single-process running maxima
+        self.dist_group = None
+
+    # ------------------------------------------------------------------ introspection
+    def __str__(self) -> str:
+        msg = f"<ConstraintManager> contains {len(self._term_names)} active terms.\n"
+        rows = []
+        for index, (name, term_cfg) in enumerate(zip(self._term_names, self._term_cfgs)):
+            limit_value = term_cfg.params.get("limit", "-")
+            names_value = "-"
+            asset_cfg = term_cfg.params.get("asset_cfg")
+            if asset_cfg is not None:
+                names_value = getattr(asset_cfg, "body_names", None) or getattr(asset_cfg, "joint_names", None) or "-"
+            elif "names" in term_cfg.params:
+                import warnings
+                warnings.warn("Using 'names' parameter is deprecated. Use 'asset_cfg' instead.",
+                              DeprecationWarning, stacklevel=2)
+                names_value = term_cfg.params["names"]
+            rows.append([index, name, limit_value, names_value, term_cfg.max_p])
+        try:
+            from prettytable import PrettyTable
+            table = PrettyTable()
+            table.title = "Active Constraint Terms"
+            table.field_names = ["Index", "Name", "Limit", "Names", "Max p"]
+            table.align["Name"] = "l"
+            table.align["Limit"] = "r"
+            table.align["Max p"] = "r"
+            for r in rows:
+                table.add_row(r)
+            body = table.get_string()
+        except ImportError:
+            head = ["Index", "Name", "Limit", "Names", "Max p"]
+            body = "Active Constraint Terms\n" + "\n".join(
+                " | ".join(str(c) for c in r) for r in [head, *rows])
+        return msg + body + "\n"
+
+    @property
+    def active_terms(self) -> List[str]:
+        return self._term_names
+
+    # ------------------------------------------------------------------ reset
+    def reset(self, env_ids: Sequence[int] | torch.Tensor | None = None) -> Dict[str, torch.Tensor]:
+        """Episode statistics of the envs in ``env_ids`` (indices, a bool mask, or None = all) as
+        0-d tensors, then zero their accumulators.  One launch, no host sync; the returned
+        tensors are slots of a ring and stay valid for ``LOG_RING`` further resets."""
+        nt = len(self._term_names)
+        extras: Dict[str, torch.Tensor] = {}
+        if nt:
+            mask = None
+            if env_ids is not None and not isinstance(env_ids, slice):
+                ids = env_ids if isinstance(env_ids, torch.Tensor) else torch.as_tensor(list(env_ids), device=self._device)
+                if ids.dtype == torch.bool:
+                    mask = ids
+                else:
+                    mask = torch.zeros(self.num_envs, dtype=torch.bool, device=self._device)
+                    mask[ids.to(self._device).long()] = True
+            nat = native.get(self._device)
+            prev, self._log_pos = self._log_pos, (self._log_pos + 1) % self.LOG_RING
+            out = self._log_ring[self._log_pos]
+            out.copy_(self._log_ring[prev])      # "no env selected" keeps the previous values
+            nat.cat_reset(self._ep_viol, self._ep_prob, self._env.episode_length_buf, mask, out)
+            if self._log_views is None:
+                self._log_views = []
+                for r in range(self.LOG_RING):
+                    d = {}
+                    for t, key in enumerate(self._term_names):
+                        d[f"Episode_Constraint_violation/{key}"] = self._log_ring[r, 2 * t]
+                        d[f"Episode_Constraint_probability/{key}"] = self._log_ring[r, 2 * t + 1]
+                    self._log_views.append(d)
+            extras = dict(self._log_views[self._log_pos])
+        for term_cfg in self._class_term_cfgs:
+            term_cfg.func.reset(env_ids=env_ids)
+        return extras
+
+    @property
+    def log_packed(self):
+        """(keys, tensor[2*n_terms]) of the latest reset() - lets a trainer stack one tensor per
+        step instead of 2*n_terms scalars."""
+        keys = []
+        for key in self._term_names:
+            keys += [f"Episode_Constraint_violation/{key}", f"Episode_Constraint_probability/{key}"]
+        return keys, self._log_ring[self._log_pos]
+
+    # ------------------------------------------------------------------ compute
+    def _bind(self, nat):
+        """first compute(): learn every term's width, allocate the packed buffers"""
+        env = self._env
+        descs = []
+        for cfg in self._term_cfgs:
+            d = getattr(cfg.func, "describe", None)
+            descs.append(d(env, **cfg.params) if d is not None else None)
+        self._fused = all(d is not None for d in descs) and len(descs) <= 16
+        if self._fused:
+            widths = [d.width for d in descs]
+        else:
+            widths = []
+            for cfg in self._term_cfgs:
+                out = cfg.func(env, **cfg.params)
+                widths.append(1 if out.ndim == 1 else out.shape[1])
+        self._widths = widths
+        off = [0]
+        for w in widths:
+            off.append(off[-1] + w)
+        self._term_off = (C.c_int32 * len(off))(*off)
+        self.cat._bind_packed(self._term_names, widths, self.num_envs, nat.device)
+        self._bound = True
+
+    def compute(self, reward: torch.Tensor | None = None, reset_mask: torch.Tensor | None = None,
+                dones: torch.Tensor | None = None) -> torch.Tensor:
+        """Termination probability per env.  The optional arguments fuse the three lines of
+        ``CaTEnv.step`` that consume it (cat_env.py:102-107,118-121) into the same launch:
+        ``reward`` is scaled in place by (1-p) and clipped at 0, ``dones`` receives p with hard
+        resets (``reset_mask``) overwritten by 1."""
+        nat = native.get(self._device)
+        if not self._term_names:
+            return self.cat.get_probs()
+        if not self._bound:
+            self._bind(nat)
+        env, cat = self._env, self.cat
+        if self._fused:
+            descs, forces, command, H, B = [], None, None, 1, 1
+            for cfg in self._term_cfgs:
+                d = cfg.func.describe(env, **cfg.params)
+                descs.append(d.c)
+                if d.forces is not None:
+                    forces, H, B = d.forces, d.forces.shape[1], d.forces.shape[2]
+                if d.command is not None:
+                    command = d.command
+            nat.cat_terms(descs, self.num_envs, forces, H, B, command, cat._p_cstr)
+        else:
+            off = 0
+            for cfg, w in zip(self._term_cfgs, self._widths):
+                out = cfg.func(env, **cfg.params)
+                cat._p_cstr[:, off:off + w].copy_(out.reshape(self.num_envs, w))   # bool -> float in the copy
+                off += w
+        dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
+        args = dict(reward=reward, reset_mask=reset_mask, dones=dones, probs=cat._p_probs)
+        group = self.dist_group
+        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+            if not hasattr(self, "_colmax"):
+                self._colmax = torch.zeros_like(cat._p_rm)
+            nat.cat_colmax(cat._p_cstr, self._colmax)
+            torch.distributed.all_reduce(self._colmax, op=torch.distributed.ReduceOp.MAX, group=group)
+            nat.cat_apply(cat._p_cstr, self._term_off, dp, cat.min_p, cat.tau, cat._p_first, self._colmax, cat._p_rm,
+                          self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)
+        else:
+            nat.cat_step(cat._p_cstr, self._term_off, dp, cat.min_p, cat.tau, cat._p_first, cat._p_rm,
+                         self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)
+        cat._p_first = False
+        return self._cstr_prob_buf
+
+    @property
+    def max_p(self) -> Dict[str, torch.Tensor]:
+        return {n: torch.full((w,), c.max_p, dtype=torch.float, device=self._device)
+                for n, w, c in zip(self._term_names, self._widths, self._term_cfgs)}
+
+    # ------------------------------------------------------------------ term cfg access
+    def set_term_cfg(self, term_name: str, cfg: ConstraintTermCfg):
+        if term_name not in self._term_names:
+            raise ValueError(f"Constraint term '{term_name}' not found.")
+        self._term_cfgs[self._term_names.index(term_name)] = cfg
+
+    def get_term_cfg(self, term_name: str) -> ConstraintTermCfg:
+        if term_name not in self._term_names:
+            raise ValueError(f"Constraint term '{term_name}' not found.")
+        return self._term_cfgs[self._term_names.index(term_name)]
+
+    def _prepare_terms(self):
+        cfg_items = self.cfg.items() if isinstance(self.cfg, dict) else self.cfg.__dict__.items()
+        for term_name, term_cfg in cfg_items:
+            if term_cfg is None:
+                continue
+            if not isinstance(term_cfg, ConstraintTermCfg):
+                raise TypeError(f"Configuration for term '{term_name}' is not ConstraintTermCfg. "
+                                f"Received: '{type(term_cfg)}'.")
+            if not isinstance(term_cfg.max_p, (float, int)):
+                raise TypeError(f"Limit for term '{term_name}' must be float or int. "
+                                f"Received: '{type(term_cfg.max_p)}'.")
+            self._resolve_common_term_cfg(term_name, term_cfg, min_argc=1)
+            self._term_names.append(term_name)
+            self._term_cfgs.append(term_cfg)
+            if isinstance(term_cfg.func, ManagerTermBase):
+                self._class_term_cfgs.append(term_cfg)

@@ -58,27 +58,42 @@ __global__ __launch_bounds__(kThreads) void cat_colmax_partial(const float* __re
 }
 
 // fold [nblk,K] partial maxima (or a single row = an already reduced / all-reduced colmax),
-// floor at 1e-6 (:55), optionally publish the column maxima, optionally EMA-update rm (:58-61)
+// floor at 1e-6 (:55), optionally publish the column maxima, optionally EMA-update rm (:58-61).
+// Thread (c,g): column c, partial-row group g; max is order independent => bit-exact.
 __global__ __launch_bounds__(kThreads) void cat_reduce_ema(const float* __restrict__ partial, int nblk, int K,
                                                            float* __restrict__ colmax_out, float* __restrict__ rm,
                                                            int do_ema, int first_call, float tau,
                                                            float one_minus_tau) {
-  for (int c = threadIdx.x; c < K; c += blockDim.x) {
-    float m = partial[c];
-    for (int b = 1; b < nblk; ++b) m = nanmax(m, partial[(int64_t)b * K + c]);
-    m = (m < 1e-6f) ? 1e-6f : m;  // clamp(min=1e-6); NaN stays NaN like torch
-    if (colmax_out) colmax_out[c] = m;
-    if (do_ema) {
-      float r;
-      if (first_call) {
-        r = m;
-      } else {
-        float a = rm[c] * tau;          // rm.mul_(tau)
-        float b = one_minus_tau * m;    // (1-tau) * cmax
-        r = a + b;                      // .add_()
-      }
-      rm[c] = r;
+  __shared__ float sm[kThreads];
+  const int Kc = K < kThreads ? K : kThreads;
+  const int G = kThreads / Kc;
+  const int c0 = threadIdx.x % Kc, g = threadIdx.x / Kc;
+  for (int cb = 0; cb < K; cb += Kc) {
+    const int c = cb + c0;
+    float m = -__builtin_inff();
+    if (g < G && c < K) {
+#pragma unroll 8
+      for (int b = g; b < nblk; b += G) m = nanmax(m, partial[(int64_t)b * K + c]);
     }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    if (g == 0 && c < K) {
+      for (int gg = 1; gg < G; ++gg) m = nanmax(m, sm[gg * Kc + c0]);
+      m = (m < 1e-6f) ? 1e-6f : m;  // clamp(min=1e-6); NaN stays NaN like torch
+      if (colmax_out) colmax_out[c] = m;
+      if (do_ema) {
+        float r;
+        if (first_call) {
+          r = m;
+        } else {
+          float a = rm[c] * tau;          // rm.mul_(tau)
+          float b = one_minus_tau * m;    // (1-tau) * cmax
+          r = a + b;                      // .add_()
+        }
+        rm[c] = r;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -154,13 +169,49 @@ __global__ __launch_bounds__(kThreads) void cat_finish(
   }
 }
 
+// one block per term: masked means of sums/len (fp64 accumulation, fixed order), then zero the rows
+__global__ __launch_bounds__(kThreads) void cat_reset_stats(float* __restrict__ ep_viol, float* __restrict__ ep_prob,
+                                                            const int64_t* __restrict__ ep_len,
+                                                            const uint8_t* __restrict__ mask, int64_t N,
+                                                            float* __restrict__ out) {
+  __shared__ double s_a[kThreads], s_b[kThreads], s_n[kThreads];
+  const int t = blockIdx.x;
+  float* v = ep_viol + (int64_t)t * N;
+  float* p = ep_prob + (int64_t)t * N;
+  double a = 0.0, b = 0.0, n = 0.0;
+  for (int64_t i = threadIdx.x; i < N; i += kThreads) {
+    if (mask == nullptr || mask[i]) {
+      const float L = (float)ep_len[i];
+      a += (double)(v[i] / L);
+      b += (double)(p[i] / L);
+      n += 1.0;
+      v[i] = 0.0f;
+      p[i] = 0.0f;
+    }
+  }
+  s_a[threadIdx.x] = a, s_b[threadIdx.x] = b, s_n[threadIdx.x] = n;
+  __syncthreads();
+  for (int w = kThreads / 2; w >= 1; w >>= 1) {
+    if (threadIdx.x < w) {
+      s_a[threadIdx.x] += s_a[threadIdx.x + w];
+      s_b[threadIdx.x] += s_b[threadIdx.x + w];
+      s_n[threadIdx.x] += s_n[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && s_n[0] > 0.0) {
+    out[2 * t] = (float)(s_a[0] / s_n[0]) * 100.0f;
+    out[2 * t + 1] = (float)(s_b[0] / s_n[0]);
+  }
+}
+
 int launch_colmax(catppo_ctx* ctx, const float* cstr, int64_t N, int K, float** partial_out, int* nblk_out,
                   hipStream_t s) {
   const int Kc = K < kThreads ? K : kThreads;
   const int G = kThreads / Kc;
   const int rows_per_block = G * 8;
   int nblk = (int)cdiv64(N, rows_per_block);
-  if (nblk > 1024) nblk = 1024;
+  if (nblk > 128) nblk = 128;   // the fold kernel walks the partial rows: keep them few
   WsCarver ws(ctx);
   float* partial = ws.take<float>((uint64_t)nblk * K);
   CATPPO_NEED_WS(ctx, partial);
@@ -248,4 +299,14 @@ extern "C" int catppo_cat_step(catppo_ctx* ctx, const float* cstr, int64_t N, in
   CATPPO_CHECK_LAUNCH(ctx);
   return launch_finish(ctx, cstr, N, K, term_off, n_terms, term_dp, min_p, rm, reward, reset_mask, cstr_prob,
                        dones, ep_viol, ep_prob, probs, s);
+}
+
+extern "C" int catppo_cat_reset(catppo_ctx* ctx, float* ep_viol, float* ep_prob, const int64_t* episode_length,
+                                const uint8_t* mask, int n_terms, int64_t N, float* out, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, ep_viol && ep_prob && episode_length && out && n_terms >= 1 && N >= 1);
+  hipLaunchKernelGGL(cat_reset_stats, dim3(n_terms), dim3(kThreads), 0, static_cast<hipStream_t>(stream), ep_viol,
+                     ep_prob, episode_length, mask, N, out);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
 }

@@ -28,15 +28,16 @@ __device__ __forceinline__ float norm3(const float* p) {
 }
 
 // max over history of |F[e,h,b,:]|
-__device__ __forceinline__ float force_peak(const float* forces, int64_t env, int H, int B, int b) {
-  const float* base = forces + ((env * H) * B + b) * 3;
+__device__ __forceinline__ float force_peak(const float* forces, int64_t fstride, int64_t env, int H, int B, int b) {
+  const float* base = forces + env * fstride + (int64_t)b * 3;
   float m = norm3(base);
   for (int h = 1; h < H; ++h) m = nanmax(m, norm3(base + (int64_t)h * B * 3));
   return m;
 }
 
 __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int64_t N, const float* __restrict__ forces,
-                                                             int H, int B, const float* __restrict__ command,
+                                                             int64_t fstride, int H, int B,
+                                                             const float* __restrict__ command, int cld,
                                                              float* __restrict__ cstr, int K) {
   extern __shared__ float tile[];  // [kRows*K]
   const int64_t r0 = (int64_t)blockIdx.x * kRows;
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
         case CATPPO_TERM_ABS_DIFF_LIMIT_GATE_CMDY: {
           const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
           const float c = fabsf(df) - d.limit;
-          const float gate = fabsf(command[env * 3 + 1]) < d.aux ? 1.0f : 0.0f;
+          const float gate = fabsf(command[env * cld + 1]) < d.aux ? 1.0f : 0.0f;
           out = c * gate;
         } break;
         case CATPPO_TERM_GREATER: {
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
         } break;
         case CATPPO_TERM_CONTACT_ANY: {
           bool any = false;
-          for (int b = 0; b < d.n_ids; ++b) any = any || (force_peak(forces, env, H, B, d.ids[b]) > d.limit);
+          for (int b = 0; b < d.n_ids; ++b) any = any || (force_peak(forces, fstride, env, H, B, d.ids[b]) > d.limit);
           out = any ? 1.0f : 0.0f;
         } break;
         case CATPPO_TERM_NORM2_LIMIT: {
@@ -79,17 +80,17 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
           out = sqrtf(s) - d.limit;
         } break;
         case CATPPO_TERM_AIR_TIME: {
-          const float gate = norm3(command + env * 3) > d.aux ? 1.0f : 0.0f;
+          const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
           float c = d.limit - d.x[env * d.x_ld + d.ids[j]];
           c = c * d.y[env * d.y_ld + d.ids[j]];
           out = c * gate;
         } break;
         case CATPPO_TERM_N_FOOT_CONTACT: {
           int n = 0;
-          for (int b = 0; b < d.n_ids; ++b) n += force_peak(forces, env, H, B, d.ids[b]) > 1.0f ? 1 : 0;
+          for (int b = 0; b < d.n_ids; ++b) n += force_peak(forces, fstride, env, H, B, d.ids[b]) > 1.0f ? 1 : 0;
           int diff = n - (int)d.limit;
           diff = diff < 0 ? -diff : diff;
-          const float gate = norm3(command + env * 3) > d.aux ? 1.0f : 0.0f;
+          const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
           out = (float)diff * gate;
         } break;
         case CATPPO_TERM_ACTION_RATE: {
@@ -97,14 +98,14 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
           out = df / d.aux - d.limit;
         } break;
         case CATPPO_TERM_FORCE_LIMIT: {
-          out = force_peak(forces, env, H, B, d.ids[j]) - d.limit;
+          out = force_peak(forces, fstride, env, H, B, d.ids[j]) - d.limit;
         } break;
         case CATPPO_TERM_LIMIT_MINUS: {
           out = d.limit - d.x[env * d.x_ld + d.ids[0]];
         } break;
         case CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT: {
           const float c = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
-          const float gate = norm3(command + env * 3) < d.aux ? 1.0f : 0.0f;
+          const float gate = norm3(command + env * cld) < d.aux ? 1.0f : 0.0f;
           out = c * gate;
         } break;
         default:
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
 }  // namespace
 
 extern "C" int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
-                                const float* forces, int H, int B, const float* command, float* cstr, int K,
-                                void* stream) {
+                                const float* forces, int64_t forces_env_stride, int H, int B,
+                                const float* command, int command_ld, float* cstr, int K, void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, desc && cstr && N >= 1 && n_terms >= 1 && n_terms <= kMaxTerms);
   TermTable tab;
@@ -137,8 +138,9 @@ extern "C" int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, i
                            d.kind == CATPPO_TERM_N_FOOT_CONTACT || d.kind == CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT;
     const bool needs_y = d.kind == CATPPO_TERM_ABS_DIFF_LIMIT || d.kind == CATPPO_TERM_ABS_DIFF_LIMIT_GATE_CMDY ||
                          d.kind == CATPPO_TERM_AIR_TIME || d.kind == CATPPO_TERM_ACTION_RATE;
-    CATPPO_CHECK_ARG(ctx, !needs_forces || (forces != nullptr && H >= 1 && B >= 1));
-    CATPPO_CHECK_ARG(ctx, !needs_cmd || command != nullptr);
+    CATPPO_CHECK_ARG(ctx, !needs_forces || (forces != nullptr && H >= 1 && B >= 1 &&
+                                            forces_env_stride >= (int64_t)H * B * 3));
+    CATPPO_CHECK_ARG(ctx, !needs_cmd || (command != nullptr && command_ld >= 3));
     CATPPO_CHECK_ARG(ctx, needs_forces || d.x != nullptr);
     CATPPO_CHECK_ARG(ctx, !needs_y || d.y != nullptr);
     const bool per_id = d.kind != CATPPO_TERM_GREATER && d.kind != CATPPO_TERM_CONTACT_ANY &&
@@ -154,7 +156,7 @@ extern "C" int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, i
   const size_t lds = sizeof(float) * (size_t)kRows * K;
   CATPPO_CHECK_ARG(ctx, lds <= 150 * 1024);
   hipLaunchKernelGGL(cat_terms_kernel, dim3((unsigned)cdiv64(N, kRows)), dim3(kThreads), lds,
-                     static_cast<hipStream_t>(stream), tab, N, forces, H, B, command, cstr, K);
+                     static_cast<hipStream_t>(stream), tab, N, forces, forces_env_stride, H, B, command, command_ld, cstr, K);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

@@ -21,13 +21,13 @@ using gemm::Params;
 constexpr int kMaxA = 16;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
 constexpr float kEntConst = 1.41893853320467274178f;     // 0.5 + 0.5*log(2*pi)
-constexpr int kHeadRowsPerBlock = 64;                    // 4 waves x 16 rows
+constexpr int kHeadRowsPerBlock = 32;                    // head_loss: 8 waves x 4 rows
 constexpr int kGatherRows = 64;
 
 // ------------------------------------------------------------------------------- layout
 int layout_of(const catppo_mlp_shape* s, catppo_mlp_layout* L) {
   if (!s || !L) return CATPPO_E_ARG;
-  if (s->obs_dim < 1 || s->act_dim < 1 || s->act_dim > kMaxA) return CATPPO_E_ARG;
+  if (s->obs_dim < 1 || s->act_dim < 1 || s->act_dim >= kMaxA) return CATPPO_E_ARG;  // slot act_dim = critic
   if (s->n_hidden < 1 || s->n_hidden > CATPPO_MAX_HIDDEN) return CATPPO_E_ARG;
   for (int l = 0; l < s->n_hidden; ++l)
     if (s->hidden[l] < 64 || s->hidden[l] % 64 != 0 || s->hidden[l] > 4096) return CATPPO_E_ARG;
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
                                                        const float* __restrict__ W4c, const float* __restrict__ b4c,
                                                        const float* __restrict__ W4a, const float* __restrict__ b4a,
                                                        const float* __restrict__ logstd,
-                                                       const float* __restrict__ eps, int64_t M, int A,
+                                                       const float* __restrict__ eps,
+                                                       const float* __restrict__ given, int64_t M, int A,
                                                        float* __restrict__ action, float* __restrict__ logprob,
                                                        float* __restrict__ value) {
   constexpr int HL = CPL * 64;
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
       }
       mu += ba;
       float a = mu;
-      if (mine && eps != nullptr) a = mu + sd * eps[i * A + lane];   // Normal.sample(): loc + scale*N(0,1)
+      if (mine && given != nullptr) a = given[i * A + lane];
+      else if (mine && eps != nullptr) a = mu + sd * eps[i * A + lane];   // Normal.sample(): loc + scale*N(0,1)
       const float diff = a - mu;
       const float term = mine ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f;
       const float lp = wave_sum(term);
@@ -292,8 +294,38 @@ struct HeadArgs {
   catppo_ppo_hparams hp;
 };
 
-template <int CPL>
-__global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
+// Sixteen per-lane partial values -> their 64-lane totals with 17 cross-lane exchanges instead of
+// 16 x 6: every butterfly step halves the number of live values (the lane keeps the half selected by
+// its own bit and hands the other half to its partner).  Afterwards the total of value j sits in the
+// four lanes l with slot(l) == j, slot(l) = 8*bit5 + 4*bit4 + 2*bit3 + bit2.
+__device__ __forceinline__ float reduce16(float (&v)[16], int lane) {
+  float a[8], b[4], c[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = (h5 ? v[j + 8] : v[j]) + __shfl_xor(h5 ? v[j] : v[j + 8], 32, 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = (h4 ? a[j + 4] : a[j]) + __shfl_xor(h4 ? a[j] : a[j + 4], 16, 64);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) c[j] = (h3 ? b[j + 2] : b[j]) + __shfl_xor(h3 ? b[j] : b[j + 2], 8, 64);
+  float s = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  return s;
+}
+__host__ __device__ constexpr int slot_lane(int j) {   // first lane holding the total of value j
+  return ((j >> 3) & 1) << 5 | ((j >> 2) & 1) << 4 | ((j >> 1) & 1) << 3 | (j & 1) << 2;
+}
+__device__ __forceinline__ float lane_bcast(float x, int src_lane) {   // src_lane is a compile-time constant
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
+}
+
+static_assert(kHeadRowsPerBlock == 32, "8 waves x 4 rows");
+constexpr int kHeadWaves = 8;        // waves per block
+constexpr int kHeadRowsPerWave = 4;  // => 32 rows per block, 512 blocks for a 16384-sample minibatch
+
+// AM = compile-time bound on the action dimension (register arrays and unrolled loops)
+template <int CPL, int AM>
+__global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 2 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
   constexpr int HL = CPL * 64;
   // LDS: [A*HL] actor head weights | [(A+1)*HL] weight-grad accumulation | [NS] scalars
   extern __shared__ float lds[];
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
   float* lw = lds + A * HL;               // rows 0..A-1 = dW4a, row A = dW4c
   float* ls = lw + (A + 1) * HL;          // db4a[A], db4c, dlogstd[A], diag[8]
 
-  for (int o = threadIdx.x; o < A * HL; o += 256) s_wa[o] = g.W4a[o];
+  for (int o = threadIdx.x; o < A * HL; o += kHeadWaves * 64) s_wa[o] = g.W4a[o];
   // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
   if (wave == 0) {
     if (g.hp.norm_adv && g.adv_stats == nullptr) {
@@ -334,54 +366,67 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
   const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
   const float vden = sqrtf(g.vrms_var[0] + 1e-8f), vmean = g.vrms_mean[0];
 
-  // lane k (< A) owns action dimension k
-  const bool mine = lane < A;
-  const float sd = mine ? expf(g.logstd[lane]) : 1.0f;
+  // after reduce16 the lanes with slot == k own action dimension k; slot A carries the critic output
+  const int slot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+  const bool mine = slot < A;
+  const bool leader = mine && (lane & 3) == 0;    // one lane per action dim accumulates / publishes
+  const float sd = mine ? expf(g.logstd[slot]) : 1.0f;
   const float var = sd * sd, lsd = logf(sd);
-  const float ba = mine ? g.b4a[lane] : 0.0f;
-  const float ent_row = wave_sum(mine ? kEntConst + lsd : 0.0f);   // entropy is state independent
-  float gba = 0.0f, gls = 0.0f;            // per-lane (per action dim) accumulators
+  const float ba = mine ? g.b4a[slot] : 0.0f;
+  float ent_row = 0.0f;                           // entropy is state independent
+#pragma unroll
+  for (int k = 0; k < AM; ++k)
+    if (k < A) ent_row += lane_bcast(kEntConst + lsd, slot_lane(k));
+  float gba = 0.0f, gls = 0.0f;                   // per action dim accumulators (leader lanes)
   float wc[CPL], gwc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) wc[c] = g.W4c[lane * CPL + c], gwc[c] = 0.0f;
-  float gwa[kMaxA][CPL];
+  float gwa[AM][CPL];
 #pragma unroll
-  for (int k = 0; k < kMaxA; ++k)
+  for (int k = 0; k < AM; ++k)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) gwa[k][c] = 0.0f;
   float gbc = 0.0f;
   float d_pg = 0.0f, d_v = 0.0f, d_ent = 0.0f, d_kl = 0.0f, d_okl = 0.0f, d_cf = 0.0f;
   const float bc = g.b4c[0];
 
-  const int64_t r0 = (int64_t)blockIdx.x * kHeadRowsPerBlock + wave * (kHeadRowsPerBlock / 4);
-  for (int rr = 0; rr < kHeadRowsPerBlock / 4; ++rr) {
+  const int64_t r0 = ((int64_t)blockIdx.x * kHeadWaves + wave) * kHeadRowsPerWave;
+  for (int rr = 0; rr < kHeadRowsPerWave; ++rr) {
     const int64_t i = r0 + rr;
     if (i >= g.M) break;   // wave-uniform
     float hc[CPL], ha[CPL];
-    float dot = 0.0f;
+    float part[16];
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
       hc[c] = g.Hc[i * HL + lane * CPL + c];
       ha[c] = g.Ha[i * HL + lane * CPL + c];
-      dot = fmaf(hc[c], wc[c], dot);
     }
-    const float v = wave_sum(dot) + bc;
-
-    // ---- policy head, log-prob
-    float mu = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kMaxA; ++k) {
+    for (int k = 0; k < 16; ++k) {
+      float d = 0.0f;
       if (k < A) {
-        float d = 0.0f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], s_wa[k * HL + lane * CPL + c], d);
-        d = wave_sum(d);
-        if (lane == k) mu = d;
+      } else if (k == A) {
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) d = fmaf(hc[c], wc[c], d);
       }
+      part[k] = d;
     }
-    mu += ba;
-    const float diff = mine ? g.act[i * A + lane] - mu : 0.0f;
-    const float newlogp = wave_sum(mine ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f);
+    const float tot = reduce16(part, lane);       // lane with slot k: mu_k (k<A) or the critic output (k==A)
+    const float mu = tot + ba;
+    float v = 0.0f;
+#pragma unroll
+    for (int k = 0; k <= AM; ++k)
+      if (k == A) v = lane_bcast(tot, slot_lane(k < 16 ? k : 15)) + bc;
+
+    // ---- log-prob of the taken action
+    const float diff = mine ? g.act[i * A + slot] - mu : 0.0f;
+    const float term = -(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi;
+    float newlogp = 0.0f;
+#pragma unroll
+    for (int k = 0; k < AM; ++k)
+      if (k < A) newlogp += lane_bcast(term, slot_lane(k));
     const float logratio = newlogp - g.oldlogp[i];
     const float ratio = expf(logratio);
     d_okl += -logratio;
@@ -422,8 +467,8 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
     const float g_v = g.hp.vf_coef * 0.5f * dnv * invM / vden;   // d loss / d v_i
 
     // ---- backward through the heads
-    const float gm = mine ? g_logp * diff / var : 0.0f;           // d loss / d mu_ik   (lane k)
-    if (mine) {
+    const float gm = mine ? g_logp * diff / var : 0.0f;           // d loss / d mu_ik   (lanes of slot k)
+    if (leader) {
       gls += g_logp * (diff * diff / var - 1.0f) - g.hp.ent_coef * invM;
       gba += gm;
     }
@@ -431,9 +476,9 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) dha[c] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < kMaxA; ++k) {
+    for (int k = 0; k < AM; ++k) {
       if (k < A) {
-        const float gmk = __shfl(gm, k, 64);
+        const float gmk = lane_bcast(gm, slot_lane(k));
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
           gwa[k][c] = fmaf(gmk, ha[c], gwa[k][c]);
@@ -452,10 +497,10 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
   }
 
   // ---- block reduction in fixed wave order (deterministic), then one partial per block
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < kHeadWaves; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int k = 0; k < kMaxA; ++k)
+      for (int k = 0; k < AM; ++k)
         if (k < A) {
 #pragma unroll
           for (int c = 0; c < CPL; ++c) {
@@ -468,11 +513,11 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
         const int o = A * HL + lane * CPL + c;
         lw[o] = w == 0 ? gwc[c] : lw[o] + gwc[c];
       }
-      if (mine) {
-        ls[lane] = w == 0 ? gba : ls[lane] + gba;
-        ls[A + 1 + lane] = w == 0 ? gls : ls[A + 1 + lane] + gls;
+      if (leader) {
+        ls[slot] = w == 0 ? gba : ls[slot] + gba;
+        ls[A + 1 + slot] = w == 0 ? gls : ls[A + 1 + slot] + gls;
       }
-      if (lane == 0) {
+      if (lane == 63) {   // lane 63 (slot 15) never leads an action dim: it carries the uniform scalars
         ls[A] = w == 0 ? gbc : ls[A] + gbc;
         float* dg = ls + 2 * A + 1;
         const float vals[kHeadDiag] = {d_pg, d_v, d_ent, 0.0f, d_kl, d_okl, d_cf, 0.0f};
@@ -483,9 +528,9 @@ __global__ __launch_bounds__(256) void head_loss_kernel(const HeadArgs g) {
     __syncthreads();
   }
   float* pw = g.part_w + (int64_t)blockIdx.x * (A + 1) * HL;
-  for (int o = threadIdx.x; o < (A + 1) * HL; o += 256) pw[o] = lw[o];
+  for (int o = threadIdx.x; o < (A + 1) * HL; o += kHeadWaves * 64) pw[o] = lw[o];
   float* ps = g.part_s + (int64_t)blockIdx.x * NS;
-  for (int o = threadIdx.x; o < NS; o += 256) ps[o] = ls[o];
+  for (int o = threadIdx.x; o < NS; o += kHeadWaves * 64) ps[o] = ls[o];
 }
 
 // ------------------------------------------------------------------------------- segmented partial reduction
@@ -506,29 +551,43 @@ struct SegTable {
   Seg s[kMaxSegs];
 };
 
+// block = EL elements x G part-groups (EL*G = 256).  Thread (e,g) adds parts g, g+G, ... in order, the G
+// group sums are then combined in LDS in fixed order => deterministic, and at most n_parts/G
+// dependent adds per thread with the loads issued ahead (unrolled).
+template <int G>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
-  const Seg& sg = t.s[blockIdx.y];
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < sg.count; e += (int64_t)gridDim.x * 256) {
+  constexpr int EL = 256 / G;
+  __shared__ float sm[256];
+  const Seg sg = t.s[blockIdx.y];
+  const int el = threadIdx.x % EL, g = threadIdx.x / EL;
+  for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < sg.count; e0 += (int64_t)gridDim.x * EL) {
+    const int64_t e = e0 + el;
     float a = 0.0f;
-    for (int p = 0; p < sg.n_parts; ++p) a += sg.src[(int64_t)p * sg.stride + e];
-    if (sg.mode == 0) {
-      sg.dst[e] = a;
-    } else {
-      // diagnostics block: {pg, v, ent, loss, kl, old_kl, clipfrac, count}
-      float v = a * sg.scale;
-      if (e == 3) {
-        float pg = 0.f, vl = 0.f, en = 0.f;
-        for (int p = 0; p < sg.n_parts; ++p) {
-          pg += sg.src[(int64_t)p * sg.stride + 0];
-          vl += sg.src[(int64_t)p * sg.stride + 1];
-          en += sg.src[(int64_t)p * sg.stride + 2];
-        }
-        v = (pg - ent_coef * en + vl * vf_coef) * sg.scale;   // loss = pg - ENT*entropy + v_loss*VF
-      } else if (e == 7) {
-        v = 1.0f;                                             // number of minibatches accumulated
-      }
-      sg.dst[e] = sg.dst[e] + v;
+    if (e < sg.count) {
+#pragma unroll 8
+      for (int p = g; p < sg.n_parts; p += G) a += sg.src[(int64_t)p * sg.stride + e];
     }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0) {
+#pragma unroll
+      for (int gg = 1; gg < G; ++gg) a += sm[gg * EL + el];
+    }
+    __syncthreads();
+    if (g == 0) sm[el] = a;          // combined sums, visible to the whole block
+    __syncthreads();
+    if (g == 0 && e < sg.count) {
+      if (sg.mode == 0) {
+        sg.dst[e] = a;
+      } else {
+        // diagnostics block {pg, v, ent, loss, kl, old_kl, clipfrac, count} (count = 8 <= EL: one block)
+        float v = a * sg.scale;
+        if (e == 3) v = (sm[0] - ent_coef * sm[2] + sm[1] * vf_coef) * sg.scale;   // pg - ENT*entropy + v_loss*VF
+        if (e == 7) v = 1.0f;                                                      // minibatches accumulated
+        sg.dst[e] = sg.dst[e] + v;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -618,8 +677,8 @@ static int mlp_prologue(catppo_ctx* ctx, const catppo_mlp_shape* shape, int64_t 
 }
 
 extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                                 const float* x, int64_t N, const float* eps, float* action, float* logprob,
-                                 float* value, void* stream) {
+                                 const float* x, int64_t N, const float* eps, const float* given_action,
+                                 float* action, float* logprob, float* value, void* stream) {
   catppo_mlp_layout L;
   MlpWs w{};
   if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
@@ -635,7 +694,7 @@ extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape,
                        sizeof(float) * A * shape->hidden[nl - 1], s,
                        (const float*)w.H[0][nl - 1], (const float*)w.H[1][nl - 1], params + L.off_w[0][nl],
                        params + L.off_b[0][nl], params + L.off_w[1][nl], params + L.off_b[1][nl],
-                       params + L.off_logstd, eps, N, A, action, logprob, value);
+                       params + L.off_logstd, eps, given_action, N, A, action, logprob, value);
   });
   if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
   CATPPO_CHECK_LAUNCH(ctx);
@@ -658,7 +717,8 @@ extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, cons
     hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256), 0, s,
                        (const float*)w.H[0][nl - 1], (const float*)nullptr, params + L.off_w[0][nl],
                        params + L.off_b[0][nl], (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, N, 0, (float*)nullptr, (float*)nullptr, value);
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, (float*)nullptr,
+                       (float*)nullptr, value);
   });
   if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
   CATPPO_CHECK_LAUNCH(ctx);
@@ -706,7 +766,13 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   g.M = M, g.A = A, g.hp = *hp;
   const size_t head_lds = sizeof(float) * ((size_t)A * HL + (size_t)(A + 1) * HL + head_scalars(A));
   const int rc = dispatch_cpl(HL, [&](auto cpl) {
-    hipLaunchKernelGGL((head_loss_kernel<decltype(cpl)::value>), dim3(nbh), dim3(256), head_lds, s, g);
+    constexpr int CPL = decltype(cpl)::value;
+    if (A <= 8)
+      head_loss_kernel<CPL, 8><<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
+    else if (A <= 12)
+      head_loss_kernel<CPL, 12><<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
+    else
+      head_loss_kernel<CPL, 15><<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
   });
   if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
   CATPPO_CHECK_LAUNCH(ctx);
@@ -764,7 +830,10 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
       add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, nbh, 1, hp->inv_global_batch);
     }
-    hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, s, segs, hp->ent_coef, hp->vf_coef);
+    if (l == nl - 1)   // 256 head partials per element: 16 part groups; split-K partials: 4
+      hipLaunchKernelGGL(seg_reduce_kernel<16>, dim3(128, segs.n), dim3(256), 0, s, segs, hp->ent_coef, hp->vf_coef);
+    else
+      hipLaunchKernelGGL(seg_reduce_kernel<4>, dim3(256, segs.n), dim3(256), 0, s, segs, hp->ent_coef, hp->vf_coef);
     CATPPO_CHECK_LAUNCH(ctx);
     if (l > 0) {
       // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})

@@ -51,12 +51,29 @@ __global__ __launch_bounds__(kThreads) void rms_moments_partial(const float* __r
   }
 }
 
+// fold the per-block partials; thread (c,g): value c of the 2*D sums, partial-row group g, then a
+// fixed-order combine of the G group sums in LDS (deterministic)
 __global__ __launch_bounds__(kThreads) void rms_moments_final(const double* __restrict__ partial, int nblk, int D,
                                                               double* __restrict__ sums) {
-  for (int c = threadIdx.x; c < 2 * D; c += blockDim.x) {
+  __shared__ double sm[kThreads];
+  const int W = 2 * D;
+  const int Wc = W < kThreads ? W : kThreads;
+  const int G = kThreads / Wc;
+  const int c0 = threadIdx.x % Wc, g = threadIdx.x / Wc;
+  for (int cb = 0; cb < W; cb += Wc) {
+    const int c = cb + c0;
     double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += partial[(int64_t)b * 2 * D + c];
-    sums[c] = a;
+    if (g < G && c < W) {
+#pragma unroll 8
+      for (int b = g; b < nblk; b += G) a += partial[(int64_t)b * W + c];
+    }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0 && c < W) {
+      for (int gg = 1; gg < G; ++gg) a += sm[gg * Wc + c0];
+      sums[c] = a;
+    }
+    __syncthreads();
   }
 }
 
@@ -116,7 +133,7 @@ int launch_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ld
   const int G = kThreads / Dc;
   const int rows_per_block = G * 16;
   int nblk = (int)cdiv64(N, rows_per_block);
-  if (nblk > 512) nblk = 512;
+  if (nblk > 128) nblk = 128;
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   CATPPO_NEED_WS(ctx, partial);
@@ -154,7 +171,7 @@ extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int
   // the fp64 column sums live at the tail of the workspace, after the per-block partials
   const int Dc = D < kThreads ? D : kThreads;
   int nblk = (int)cdiv64(N, (kThreads / Dc) * 16);
-  if (nblk > 512) nblk = 512;
+  if (nblk > 128) nblk = 128;
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   double* sums = ws.take<double>((uint64_t)2 * D);

@@ -89,6 +89,17 @@ int catppo_cat_apply(catppo_ctx* ctx, const float* cstr, int64_t N, int K,
                      const uint8_t* reset_mask, float* cstr_prob, float* dones,
                      float* ep_viol, float* ep_prob, float* probs, void* stream);
 
+/* ConstraintManager.reset: per-term episode statistics of the envs selected by `mask`
+ * (uint8/bool [N]; NULL = all envs), then zero their accumulators:
+ *   out[2t]   = mean_i(ep_viol[t,i] / len_i) * 100      "Episode_Constraint_violation/<term>"
+ *   out[2t+1] = mean_i(ep_prob[t,i] / len_i)            "Episode_Constraint_probability/<term>"
+ * If no env is selected `out` keeps its previous content (the reference keeps the last log
+ * dict in env.extras until the next reset).  episode_length: int64 [N] (IsaacLab's
+ * episode_length_buf); a zero length gives NaN/inf exactly like the reference's first reset.
+ * replaces: cat/constraint_manager.py:190-211. */
+int catppo_cat_reset(catppo_ctx* ctx, float* ep_viol, float* ep_prob, const int64_t* episode_length,
+                     const uint8_t* mask, int n_terms, int64_t N, float* out, void* stream);
+
 /* Solo12 constraint terms evaluated straight from sim-state tensors into the cstr matrix.
  * `desc` is a host array of n_terms descriptors (see catppo_term_desc).
  * replaces: cat/constraints.py:23-235 (C1..C15). */
@@ -119,11 +130,12 @@ typedef struct catppo_term_desc {
   int32_t x_ld, y_ld;
 } catppo_term_desc;
 
-/* forces: (N,H,B,3) net_forces_w_history; command: (N,3). Either may be NULL if no term
- * uses it.  cstr [N,K] out, K = sum of widths. */
+/* forces: (N,H,B,3) net_forces_w_history, env i at forces + i*forces_env_stride (= H*B*3 when
+ * dense); command: (N,3) with leading dimension command_ld.  Either may be NULL if no term uses
+ * it.  cstr [N,K] out, K = sum of widths. */
 int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
-                     const float* forces, int H, int B, const float* command, float* cstr,
-                     int K, void* stream);
+                     const float* forces, int64_t forces_env_stride, int H, int B,
+                     const float* command, int command_ld, float* cstr, int K, void* stream);
 
 /* ---- GAE -------------------------------------------------------------------------------
  * time-major (T,N) buffers; float dones in [0,1]; separate time-out mask.
@@ -164,7 +176,7 @@ int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, int D, int6
 
 typedef struct catppo_mlp_shape {
   int32_t obs_dim;                  /* D  */
-  int32_t act_dim;                  /* A  (<= 32) */
+  int32_t act_dim;                  /* A  (<= 15) */
   int32_t n_hidden;                 /* L  (1..CATPPO_MAX_HIDDEN) */
   int32_t hidden[CATPPO_MAX_HIDDEN]; /* widths, each a multiple of 64 */
 } catppo_mlp_shape;
@@ -187,11 +199,12 @@ int catppo_mlp_layout_of(const catppo_mlp_shape* shape, catppo_mlp_layout* out);
 uint64_t catppo_mlp_workspace_bytes(const catppo_mlp_shape* shape, int64_t rows);
 
 /* Rollout policy step (no grad):  x [N,Dp] normalised obs ->
- *   action = mu + exp(logstd)*eps  (eps [N,A] supplied N(0,1) noise; NULL -> action = mu)
+ *   action = mu + exp(logstd)*eps  (eps [N,A] supplied N(0,1) noise; NULL -> action = mu;
+ *            given_action [N,A] non-NULL -> that action is scored instead, ppo.py:109-113)
  *   logprob [N], value [N].   replaces: ppo.py:104-119,208-212. */
 int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                      const float* x, int64_t N, const float* eps, float* action,
-                      float* logprob, float* value, void* stream);
+                      const float* x, int64_t N, const float* eps, const float* given_action,
+                      float* action, float* logprob, float* value, void* stream);
 
 /* critic only (bootstrap value, ppo.py:252) */
 int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,

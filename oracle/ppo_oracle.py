@@ -250,7 +250,9 @@ class PPOOracle:
         self.iteration = 0
         self.timers = {"rollout": 0.0, "env": 0.0, "gae": 0.0, "update": 0.0}
 
-    def run_iteration(self, eps_fn=None, perm_fn=None):
+    def run_iteration(self, eps_fn=None, perm_fn=None, actions_fn=None):
+        """``actions_fn(step)``, if given, supplies the action taken at each step (e.g. the device's),
+        so that action-dependent constraint terms see identical inputs on both sides."""
         import time
         c = self.cfg
         T, N = c["num_steps"], self.N
@@ -264,7 +266,8 @@ class PPOOracle:
             self.true_dones[step] = self.next_true_done
             with torch.no_grad():
                 eps = None if eps_fn is None else eps_fn(step)
-                action, logprob, _, value = self.agent.get_action_and_value(self.next_obs, eps=eps)
+                given = None if actions_fn is None else actions_fn(step)
+                action, logprob, _, value = self.agent.get_action_and_value(self.next_obs, action=given, eps=eps)
             self.values[step], self.actions[step], self.logprobs[step] = value.flatten(), action, logprob
             te = time.perf_counter()
             nobs, self.rewards[step], nd, timeouts, _info = self.env.step(action)

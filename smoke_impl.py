@@ -1,0 +1,106 @@
+"""smoke(): one tiny invocation of the whole hot path on cuda:0, checked against the oracle.
+
+64 envs x 8 steps, six constraint terms, reference MLP: one PPO iteration on the device
+(libcatppo.so) and the same iteration on the CPU oracle fed with the same synthetic stream,
+the same action noise and the same minibatch permutations."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "constraints-as-terminations_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden=(512, 256, 128), six_terms=True, obs_dim=45,
+              stream_steps=None, seed=42):
+    import cat_envs.tasks  # noqa: F401  (registers the tasks)
+    from cat_envs.shim import load_cfg_from_registry
+    from cat_envs.tasks.locomotion.velocity.config.solo12 import cat_flat_env_cfg as E
+    task = "Isaac-Velocity-CaT-Flat-Solo12-v0"
+    env_cfg = load_cfg_from_registry(task, "env_cfg_entry_point")
+    agent_cfg = load_cfg_from_registry(task, "clean_rl_cfg_entry_point")
+    env_cfg.scene.num_envs = num_envs
+    env_cfg.seed = seed
+    env_cfg.synthetic.obs_dim = obs_dim
+    env_cfg.synthetic.stream_steps = stream_steps or max(2 * num_steps, 16)
+    if six_terms:
+        env_cfg.constraints, env_cfg.curriculum = E.SixConstraintsCfg(), E.SixCurriculumCfg()
+    agent_cfg.num_steps, agent_cfg.minibatch_size = num_steps, minibatch
+    agent_cfg.updates_epochs, agent_cfg.num_iterations = epochs, iters
+    agent_cfg.hidden = tuple(hidden)
+    agent_cfg.save_interval = 10 ** 9
+    return task, env_cfg, agent_cfg
+
+
+def run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=1, hidden=(512, 256, 128), six_terms=True,
+             seed=42):
+    """returns (trainer, oracle, per-iteration oracle outputs)"""
+    from cat_envs.shim import make
+    from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+    from oracle import env_oracle, ppo_oracle
+    task, env_cfg, agent_cfg = make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden, six_terms, seed=seed)
+    env = make(task, cfg=env_cfg)
+    trainer = PPOTrainer(env, agent_cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in trainer.agent.state_dict().items()}
+    cpu_env = env_oracle.from_device_env(env)
+    ag = ppo_oracle.AgentOracle(trainer.D, trainer.A, hidden)
+    ag.load({k: v for k, v in sd.items() if not k.startswith(("obs_rms", "value_rms"))})
+    cfg = {k: getattr(agent_cfg, k) for k in ppo_oracle.PPOOracle.DEFAULT_CFG}
+    orc = ppo_oracle.PPOOracle(cpu_env, num_envs, trainer.D, trainer.A, cfg=cfg, hidden=hidden, agent=ag)
+    rs = np.random.RandomState(seed)
+    outs = []
+    B = num_envs * num_steps
+    for it in range(iters):
+        eps = rs.standard_normal((num_steps, num_envs, trainer.A)).astype(np.float32)
+        perms = np.stack([rs.permutation(B) for _ in range(epochs)]).astype(np.int64)
+        eps_d, perms_d = torch.from_numpy(eps).cuda(), torch.from_numpy(perms).cuda()
+        trainer.run_iteration(eps_fn=lambda s: eps_d[s], perm_fn=lambda e: perms_d[e])
+        # the oracle replays the device's actions: the action-rate constraint then sees bit-identical
+        # inputs, and log-probs / values are evaluated at the same actions
+        acts = trainer.actions.cpu()
+        outs.append(orc.run_iteration(eps_fn=lambda s: torch.from_numpy(eps[s]),
+                                      perm_fn=lambda e: torch.from_numpy(perms[e]), actions_fn=lambda s: acts[s]))
+    torch.cuda.synchronize()
+    return trainer, orc, outs
+
+
+def compare(trainer, orc, out, tol_scale=1.0):
+    T = trainer.T
+    rep = {}
+
+    def err(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max())
+    rep["rewards"] = err(trainer.rewards.cpu(), orc.rewards)               # reward*(1-p): bit-exact masks
+    rep["dones"] = err(trainer.dones[1:T].cpu(), orc.dones[1:])
+    rep["values"] = err(trainer.values.cpu(), orc.values)
+    rep["logprobs"] = err(trainer.logprobs.cpu(), orc.logprobs)
+    rep["advantages"] = err(trainer.advantages.cpu(), out["advantages"])
+    rep["returns"] = err(trainer.returns.cpu(), out["returns"])
+    flat_ref = torch.cat([p.detach().reshape(-1) for p in orc.agent.parameters()]).numpy()
+    sd = trainer.agent.state_dict()
+    keys = ["actor_logstd"] + [f"{n}.{i}.{w}" for n in ("critic", "actor_mean") for i in (0, 2, 4, 6)
+                               for w in ("weight", "bias")]
+    flat_dev = torch.cat([sd[k].detach().cpu().reshape(-1) for k in keys]).numpy()
+    rep["params"] = err(flat_dev, flat_ref)
+    assert rep["rewards"] == 0.0 and rep["dones"] == 0.0, rep          # termination masks are bit-exact
+    assert rep["values"] < 2e-5 * tol_scale and rep["logprobs"] < 2e-4 * tol_scale, rep
+    assert rep["advantages"] < 5e-5 * tol_scale and rep["returns"] < 5e-5 * tol_scale, rep
+    assert rep["params"] < 2e-4 * tol_scale, rep
+    return rep
+
+
+def run():
+    assert torch.cuda.is_available(), "smoke() needs the MI355X"
+    torch.cuda.set_device(0)
+    trainer, orc, outs = run_pair()
+    rep = compare(trainer, orc, outs[-1])
+    print("[smoke] CaT-PPO iteration on cuda:0 matches the oracle:", {k: f"{v:.2e}" for k, v in rep.items()})
+
+
+if __name__ == "__main__":
+    run()

@@ -1,0 +1,87 @@
+"""Whole hot path on the GPU (env step with fused constraint terms + CaT step, rollout, GAE,
+normalisers, epochs x minibatches, clip + Adam) against the CPU oracle on the same streams."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_smoke_pair_reference_arch():
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=64, num_steps=24, minibatch=512, epochs=3, iters=2)
+    rep = smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+    print(rep)
+    # normaliser state
+    np.testing.assert_allclose(trainer.agent.obs_rms.running_mean.cpu().numpy(), orc.agent.obs_rms.mean.numpy(),
+                               rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(trainer.agent.value_rms.running_var), float(orc.agent.value_rms.var), rtol=1e-4)
+    assert float(trainer.agent.obs_rms.count) == float(orc.agent.obs_rms.count)
+
+
+def test_full_constraint_set_and_3x256_arch():
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=256, num_steps=8, minibatch=1024, epochs=1, iters=1,
+                                             hidden=(256, 256, 256), six_terms=False)
+    smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+    cm = trainer.envs.constraint_manager
+    assert len(cm.active_terms) == 13 and cm.cat._p_cstr.shape == (256, 78)
+    # running maxima and per-term statistics of the manager are bit-identical to the oracle's
+    np.testing.assert_array_equal(cm.cat.get_running_maxes().cpu().numpy()[0], orc.env.mgr.cat.get_running_maxes()[0])
+    for i, name in enumerate(cm.active_terms):
+        np.testing.assert_array_equal(cm._episode_sums[name].cpu().numpy(), orc.env.mgr.episode_sums[name])
+        np.testing.assert_array_equal(cm._cstr_mean_values[name].cpu().numpy(), orc.env.mgr.cstr_mean_values[name])
+
+
+def test_reference_api_surface_on_device():
+    """CaT.add / get_probs, standalone term functions, Agent API, checkpoint round trip."""
+    import smoke_impl
+    from cat_envs.shim import make
+    from cat_envs.tasks.utils.cat import CaT, constraints
+    from cat_envs.tasks.utils.cleanrl.ppo import Agent
+    from oracle import cat_oracle as CO
+    import streams as S
+    task, env_cfg, _ = smoke_impl.make_cfgs(128, 8, 256, 1, 1)
+    env = make(task, cfg=env_cfg)
+    env.reset()
+    env.step(torch.zeros(128, 12, device="cuda"))
+    # single-term functions == their column block in the manager's packed matrix
+    cm = env.constraint_manager
+    for name, cfg in zip(cm.active_terms, cm._term_cfgs):
+        out = cfg.func(env, **cfg.params)
+        ref = cm.cat.raw_constraints[name]
+        got = out.float().reshape(128, -1)
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.cpu().numpy())
+    assert constraints.contact(env, **cm.get_term_cfg("contact").params).dtype == torch.bool
+    # CaT.add one term at a time (the reference's call pattern) vs the oracle
+    cat, orc = CaT(0.95, 0.0), CO.CaTOracle(0.95, 0.0)
+    stream = S.cat_stream(5, 100, S.CAT_TERMS_SMALL, 4)
+    for step in stream:
+        for (name, _, _), mp in zip(S.CAT_TERMS_SMALL, [0.25, 1.0, 0.25, 1.0, 0.5]):
+            cat.add(name, torch.from_numpy(np.asarray(step[name])).cuda(), mp)
+            orc.add(name, step[name], mp)
+        np.testing.assert_array_equal(cat.get_probs().cpu().numpy(), orc.get_probs())
+        np.testing.assert_array_equal(cat.get_running_maxes().cpu().numpy(), orc.get_running_maxes())
+    assert cat.get_names() == [t[0] for t in S.CAT_TERMS_SMALL] and len(cat.get_vals()) == 5
+    # Agent: 23-key state_dict, load/save round trip through the flat buffer
+    ag = Agent(env)
+    sd = ag.state_dict()
+    assert len(sd) == 23 and sd["actor_mean.0.weight"].shape == (512, 45) and sd["critic.6.weight"].shape == (1, 128)
+    w = S.agent_weights(3, 45, 12)
+    sd2 = {k: (torch.from_numpy(w[k]) if k in w else v) for k, v in sd.items()}
+    ag.load_state_dict(sd2)
+    x = torch.randn(33, 45, device="cuda")
+    a, lp, ent, v = ag.get_action_and_value(x, deterministic=True)
+    from oracle import ppo_oracle as PO
+    o = PO.AgentOracle(45, 12)
+    o.load(w)
+    with torch.no_grad():
+        a2, lp2, ent2, v2 = o.get_action_and_value(x.cpu(), deterministic=True)
+    np.testing.assert_allclose(a.cpu().numpy(), a2.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(v.cpu().numpy(), v2.numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), ent2.numpy(), rtol=1e-6)
+    _, lp3, _, _ = ag.get_action_and_value(x, action=a2.cuda() * 1.1)
+    with torch.no_grad():
+        _, lp4, _, _ = o.get_action_and_value(x.cpu(), a2 * 1.1)
+    np.testing.assert_allclose(lp3.cpu().numpy(), lp4.numpy(), rtol=1e-5, atol=1e-4)
+    assert ag(x).shape == (33, 12)
