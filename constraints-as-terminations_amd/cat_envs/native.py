@@ -86,6 +86,9 @@ def get(device=None) -> "Native":
     """process-wide context per HIP device (the manager, the env and PPO share one workspace and
     therefore one stream order)"""
     import torch as _t
+    if not _t.cuda.is_available():
+        raise RuntimeError("no HIP device visible: the CaT-PPO hot path runs on MI355X (gfx950) only; "
+                           "there is no CPU fallback")
     idx = _t.cuda.current_device() if device is None or _t.device(device).index is None else _t.device(device).index
     if idx not in _contexts:
         _contexts[idx] = Native(_t.device("cuda", idx))

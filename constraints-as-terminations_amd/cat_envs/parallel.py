@@ -1,0 +1,75 @@
+"""Env-sharded data parallelism: one process per GPU, RCCL (torch.distributed backend "nccl")
+over xGMI.  Environments are independent units, so each rank owns a contiguous block of envs,
+its rollout buffers, its CaT per-env statistics and its GAE; the exchange points are
+
+    * flat gradient           SUM   once per optimiser step (one buffer, one call)
+    * CaT column maxima       MAX   K floats per env step      (exact => masks stay bit-exact)
+    * normaliser moments      SUM   fp64 [sum x | sum x^2]     per normaliser update
+    * advantage mean / std    SUM   2 fp64 per minibatch
+
+The last three make N ranks reproduce ONE process on the union of the shards; the
+helpers are device agnostic (gloo on CPU in the tests, RCCL on the GPUs).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank(group=None) -> int:
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def active(group=None) -> bool:
+    return world_size(group) > 1
+
+
+def shard_slice(n_total: int, r: int, w: int) -> slice:
+    """contiguous block of rank ``r`` of ``w`` (sizes differ by at most one)"""
+    base, rem = divmod(n_total, w)
+    start = r * base + min(r, rem)
+    return slice(start, start + base + (1 if r < rem else 0))
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    if active(group):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
+    if active(group):
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t
+
+
+def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
+    if active(group):
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def global_moment_sums(sums_and_count: torch.Tensor, group=None) -> torch.Tensor:
+    """``[sum x (D) | sum x^2 (D) | n]`` in fp64, summed over ranks in place"""
+    assert sums_and_count.dtype == torch.float64
+    return allreduce_sum_(sums_and_count, group)
+
+
+def global_adv_stats(adv_local: torch.Tensor, group=None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """mean and (unbiased std + 1e-8) of the minibatch advantages over ALL ranks
+    (reference ppo.py:316-318 on the union of the per-rank minibatch shards)"""
+    a = adv_local.double()
+    s = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(a.numel()), dtype=torch.float64, device=a.device)])
+    allreduce_sum_(s, group)
+    n = s[2]
+    mean = s[0] / n
+    var = ((s[1] - n * mean * mean) / (n - 1)).clamp_min(0)
+    res = torch.stack([mean, var.sqrt() + 1e-8]).float()
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res

@@ -24,7 +24,7 @@ from typing import Dict, List
 
 import torch
 
-from cat_envs import native
+from cat_envs import native, parallel
 from cat_envs.shim import ManagerBase, ManagerTermBase
 
 from .manager_constraint_cfg import ConstraintTermCfg
@@ -297,11 +297,11 @@ class ConstraintManager(ManagerBase):
         dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
         args = dict(reward=reward, reset_mask=reset_mask, dones=dones, probs=cat._p_probs)
         group = self.dist_group
-        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        if group is not None and parallel.active(group):
             if not hasattr(self, "_colmax"):
                 self._colmax = torch.zeros_like(cat._p_rm)
             nat.cat_colmax(cat._p_cstr, self._colmax)
-            torch.distributed.all_reduce(self._colmax, op=torch.distributed.ReduceOp.MAX, group=group)
+            parallel.allreduce_max_(self._colmax, group)
             nat.cat_apply(cat._p_cstr, self._term_off, dp, cat.min_p, cat.tau, cat._p_first, self._colmax, cat._p_rm,
                           self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)
         else:

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from cat_envs import native
+from cat_envs import native, parallel
 
 DEFAULT_HIDDEN = (512, 256, 128)     # reference Agent (ppo.py:78-95)
 
@@ -68,13 +68,12 @@ class RunningMeanStd(nn.Module):
         nat = native.get(rows.device)
         n, d = rows.shape
         group = self.dist_group
-        if group is not None and torch.distributed.is_initialized() and torch.distributed.get_world_size(group) > 1:
+        if group is not None and parallel.active(group):
             if not hasattr(self, "_sums"):
-                self._sums = torch.zeros(2 * d + 1, dtype=torch.float64, device=rows.device)
+                self._sums = torch.zeros(2 * d, dtype=torch.float64, device=rows.device)
             nat.rms_moments(rows, n, d, rows.stride(0), self._sums)
-            self._sums[2 * d] = float(n)
-            torch.distributed.all_reduce(self._sums, group=group)
-            n_total = n * torch.distributed.get_world_size(group)     # equal shards
+            parallel.global_moment_sums(self._sums, group)
+            n_total = n * parallel.world_size(group)                  # equal shards
             nat.rms_merge(self._sums, n_total, d, self.running_mean, self.running_var, self.count)
         else:
             nat.rms_update(rows, n, d, rows.stride(0), self.running_mean, self.running_var, self.count)
@@ -254,14 +253,13 @@ class PPOTrainer:
         self.T, self.N = int(c.num_steps), int(envs.unwrapped.num_envs)
         self.batch = self.T * self.N
         self.mb = int(c.minibatch_size)
-        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
-        self.rank = torch.distributed.get_rank() if self.world > 1 else 0
+        self.world, self.rank = parallel.world_size(), parallel.rank()
         hidden = tuple(getattr(c, "hidden", None) or DEFAULT_HIDDEN)
         self.agent = agent if agent is not None else Agent(envs, hidden=hidden).to(self.device)
         a = self.agent
         self.D, self.A, self.Dp = a.obs_dim, a.act_dim, a.layout.obs_pad
         if self.world > 1:
-            torch.distributed.broadcast(a.flat, src=0)          # replicas start identical (cf. skrl ppo.py:126-131)
+            parallel.broadcast_(a.flat, src=0)                  # replicas start identical (cf. skrl ppo.py:126-131)
             a.obs_rms.dist_group = a.value_rms.dist_group = torch.distributed.group.WORLD
             cm = getattr(envs.unwrapped, "constraint_manager", None)
             if cm is not None and getattr(c, "dist_exact", True):
@@ -354,19 +352,11 @@ class PPOTrainer:
                 self.hp.inv_global_batch = 1.0 / (mb.numel() * self.world)
                 adv_stats = None
                 if exact_adv:      # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318)
-                    av = b_adv[mb].double()
-                    s = torch.stack([av.sum(), (av * av).sum()])
-                    torch.distributed.all_reduce(s)
-                    n = mb.numel() * self.world
-                    mean = s[0] / n
-                    std = ((s[1] - n * mean * mean) / (n - 1)).clamp_min(0).sqrt()
-                    self.adv_stats.copy_(torch.stack([mean, std + 1e-8]))
-                    adv_stats = self.adv_stats
+                    adv_stats = parallel.global_adv_stats(b_adv[mb], out=self.adv_stats)
                 self.hp.adv_stats_external = int(adv_stats is not None)
                 nat.ppo_minibatch_grad(a.shape, self.hp, a.flat, b_obs, b_act, b_logp, b_adv, b_ret, b_val, mb,
                                        vmean, vvar, adv_stats, self.grad, self.diag)
-                if self.world > 1:
-                    torch.distributed.all_reduce(self.grad)      # RCCL SUM of the flat gradient over xGMI
+                parallel.allreduce_sum_(self.grad)              # RCCL SUM of the flat gradient over xGMI
                 self.adam_step += 1
                 nat.clip_adam(a.flat, self.grad, self.exp_avg, self.exp_avg_sq, a.layout.n_flat,
                               c.max_grad_norm, self.lr, 0.9, 0.999, 1e-5, self.adam_step)
@@ -390,7 +380,7 @@ class PPOTrainer:
         if not log:
             return None
         if self.world > 1:
-            torch.distributed.all_reduce(self.diag)
+            parallel.allreduce_sum_(self.diag)
             self.diag[7] /= self.world
         d = self.diag.cpu().numpy()                              # the one host sync of the iteration
         n_upd = max(d[7], 1.0)

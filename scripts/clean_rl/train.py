@@ -1,0 +1,117 @@
+"""Train an RL agent with CleanRL PPO on a CaT task (entry point of the hot path).
+
+Same command line as the reference (scripts/clean_rl/train.py):
+
+    python scripts/clean_rl/train.py --task=Isaac-Velocity-CaT-Flat-Solo12-v0 --headless
+
+IsaacLab's AppLauncher / hydra / gymnasium are used when importable; on an AMD box (no Isaac Sim)
+the task registry and config classes of ``cat_envs.shim`` take over and the env is driven by the
+device-resident synthetic Solo12 stream.  ``key=value`` overrides after the flags are applied to
+the env / agent configs (``env.scene.num_envs=1024 agent.minibatch_size=8192``), standing in for
+the hydra overrides of the reference.
+"""
+import argparse
+import os
+import pickle
+import sys
+from datetime import datetime
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (HERE, os.path.join(ROOT, "constraints-as-terminations_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import cli_args  # noqa: E402  isort: skip
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="Train an RL agent with CleanRL.")
+    parser.add_argument("--video", action="store_true", default=False, help="Record videos during training.")
+    parser.add_argument("--video_length", type=int, default=200, help="Length of the recorded video (in steps).")
+    parser.add_argument("--video_interval", type=int, default=2000, help="Interval between video recordings (in steps).")
+    parser.add_argument("--num_envs", type=int, default=None, help="Number of environments to simulate.")
+    parser.add_argument("--task", type=str, default=None, help="Name of the task.")
+    parser.add_argument("--seed", type=int, default=None, help="Seed used for the environment")
+    parser.add_argument("--num_iterations", type=int, default=None, help="RL Policy training iterations.")
+    cli_args.add_clean_rl_args(parser)
+    try:  # AppLauncher contributes --headless / --device / ... when Isaac Sim exists
+        from isaaclab.app import AppLauncher
+        AppLauncher.add_app_launcher_args(parser)
+    except ImportError:
+        parser.add_argument("--headless", action="store_true", default=False, help="(no-op without Isaac Sim)")
+        parser.add_argument("--device", type=str, default=None, help="Device, e.g. cuda:0")
+    return parser
+
+
+def apply_overrides(cfgs: dict, overrides):
+    """``env.a.b=value`` / ``agent.x=value`` (hydra-style dotted overrides)"""
+    import ast
+    for ov in overrides:
+        key, _, raw = ov.partition("=")
+        root, *path = key.split(".")
+        obj = cfgs[root]
+        for name in path[:-1]:
+            obj = getattr(obj, name)
+        try:
+            value = ast.literal_eval(raw)
+        except (ValueError, SyntaxError):
+            value = raw
+        setattr(obj, path[-1], value)
+
+
+def dump_cfg(path, cfg):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    if path.endswith(".yaml"):
+        import yaml
+        with open(path, "w") as f:
+            yaml.safe_dump(cfg.to_dict() if hasattr(cfg, "to_dict") else dict(cfg), f, default_flow_style=False)
+    else:
+        with open(path, "wb") as f:
+            pickle.dump(cfg.to_dict() if hasattr(cfg, "to_dict") else cfg, f)
+
+
+def main(argv=None):
+    args_cli, overrides = build_parser().parse_known_args(argv)
+    if args_cli.video:
+        args_cli.enable_cameras = True
+    import torch
+
+    import cat_envs.tasks  # noqa: F401  registers the tasks
+    from cat_envs.shim import load_cfg_from_registry, make
+    from cat_envs.tasks.utils.cleanrl.ppo import PPO
+
+    if torch.distributed.is_available() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args_cli.device is None:
+            args_cli.device = f"cuda:{local}"
+
+    env_cfg = load_cfg_from_registry(args_cli.task, "env_cfg_entry_point")
+    agent_cfg = load_cfg_from_registry(args_cli.task, "clean_rl_cfg_entry_point")
+    agent_cfg = cli_args.update_clean_rl_cfg(agent_cfg, args_cli)
+    env_cfg.scene.num_envs = args_cli.num_envs if args_cli.num_envs is not None else env_cfg.scene.num_envs
+    agent_cfg.num_iterations = (args_cli.num_iterations if args_cli.num_iterations is not None
+                                else agent_cfg.num_iterations)
+    env_cfg.seed = agent_cfg.seed
+    env_cfg.sim.device = args_cli.device if args_cli.device is not None else env_cfg.sim.device
+    apply_overrides({"env": env_cfg, "agent": agent_cfg}, [o for o in overrides if "=" in o])
+
+    log_root_path = os.path.abspath(os.path.join("logs", "clean_rl", agent_cfg.experiment_name))
+    print(f"[INFO] Logging experiment in directory: {log_root_path}")
+    log_dir = os.path.join(log_root_path, datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
+    dump_cfg(os.path.join(log_dir, "params", "env.yaml"), env_cfg)
+    dump_cfg(os.path.join(log_dir, "params", "agent.yaml"), agent_cfg)
+    dump_cfg(os.path.join(log_dir, "params", "env.pkl"), env_cfg)
+    dump_cfg(os.path.join(log_dir, "params", "agent.pkl"), agent_cfg)
+
+    env = make(args_cli.task, cfg=env_cfg, render_mode="rgb_array" if args_cli.video else None)
+    if args_cli.video:
+        print("[WARN] video recording needs Isaac Sim rendering; ignored with the synthetic simulator")
+    PPO(env, agent_cfg, log_dir)
+    env.close()
+
+
+if __name__ == "__main__":
+    main()

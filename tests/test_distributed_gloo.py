@@ -1,0 +1,140 @@
+"""Env-sharded path on CPU: world_size 2, gloo.  The exchange helpers of cat_envs.parallel are run
+on two ranks holding the two halves of the envs / of a minibatch and must reproduce the
+single-process oracle on the union of the shards."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "constraints-as-terminations_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import streams as S
+    from cat_envs import parallel
+    from oracle import cat_oracle as CO
+    from oracle import ppo_oracle as PO
+    res = {}
+    assert parallel.world_size() == world and parallel.rank() == rank and parallel.active()
+
+    # ---- 1. CaT: local column max -> MAX all-reduce -> each shard's probabilities == its rows of the
+    #         single-process result (bit-exact: max is order independent)
+    N, terms = 101, S.CAT_TERMS_SMALL            # odd N: shards of 51 / 50 envs
+    stream = S.cat_stream(21, N, terms, 5)
+    sl = parallel.shard_slice(N, rank, world)
+    full = CO.CaTOracle(0.95, 0.0)
+    rm = {}
+    for step in stream:
+        for (name, width, _), mp_ in zip(terms, [0.25, 1.0, 0.25, 1.0, 0.5]):
+            full.add(name, step[name], mp_)
+            c = CO._as_2d_f32(np.asarray(step[name]))[sl]
+            cmax = torch.from_numpy(np.maximum(c.max(0), np.float32(1e-6)))
+            parallel.allreduce_max_(cmax)
+            cmax = cmax.numpy()
+            rm[name] = cmax if name not in rm else (rm[name] * np.float32(0.95) + np.float32(1.0 - 0.95) * cmax).astype(np.float32)
+            q = np.clip((c / rm[name]).astype(np.float32), 0, 1)
+            p = np.where(c > 0, (np.float32(0.0) + (q * np.float32(mp_ - 0.0)).astype(np.float32)).astype(np.float32), np.float32(0))
+            assert np.array_equal(rm[name], full.running_maxes[name][0])
+            assert np.array_equal(p, full.probs[name][sl])
+    res["cat"] = True
+
+    # ---- 2. normaliser: fp64 moment sums all-reduced == single-process update on all rows
+    rs = np.random.RandomState(5)
+    x = (rs.standard_normal((64, 45)) * 3 + 1).astype(np.float32)
+    xs = torch.from_numpy(x[parallel.shard_slice(64, rank, world)]).double()
+    sums = torch.cat([xs.sum(0), (xs * xs).sum(0), torch.tensor([float(xs.shape[0])], dtype=torch.float64)])
+    parallel.global_moment_sums(sums)
+    n = float(sums[-1])
+    mean = sums[:45] / n
+    var = sums[45:90] / n - mean * mean
+    ref = PO.RMSOracle((45,))
+    ref.update(torch.from_numpy(x))
+    bm, bv = torch.mean(torch.from_numpy(x), 0), torch.var(torch.from_numpy(x), correction=0, dim=0)
+    assert n == 64 and torch.allclose(mean.float(), bm, rtol=1e-6, atol=1e-6) and torch.allclose(var.float(), bv, rtol=1e-5)
+    res["rms"] = True
+
+    # ---- 3. minibatch: per-rank gradient with 1/M_global scaling + global advantage statistics,
+    #         SUM all-reduce of the flat gradient == single-process gradient on the whole minibatch
+    D, A, hidden, M = 45, 12, (64, 64, 64), 256
+    w = S.agent_weights(9, D, A, hidden)
+    rs = np.random.RandomState(10)
+    batch = dict(obs=rs.standard_normal((M, D)).astype(np.float32), act=rs.standard_normal((M, A)).astype(np.float32) * 0.5,
+                 adv=rs.standard_normal(M).astype(np.float32), ret=rs.standard_normal(M).astype(np.float32),
+                 val=rs.standard_normal(M).astype(np.float32))
+    cfg = dict(clip_coef=0.2, ent_coef=0.001, vf_coef=2.0, norm_adv=True, clip_vloss=True)
+
+    def make_agent():
+        ag = PO.AgentOracle(D, A, hidden)
+        ag.load(w)
+        return ag
+    ag0 = make_agent()
+    with torch.no_grad():
+        _, lp0, _, _ = ag0.get_action_and_value(torch.from_numpy(batch["obs"]), torch.from_numpy(batch["act"]))
+    batch["logp"] = (lp0.numpy() + rs.standard_normal(M).astype(np.float32) * 0.2).astype(np.float32)
+    t = {k: torch.from_numpy(v) for k, v in batch.items()}
+    # single process
+    ag = make_agent()
+    ps = [p.requires_grad_(True) for p in ag.parameters()]
+    loss, _ = PO.ppo_minibatch_loss(ag, t["obs"], t["act"], t["logp"], t["adv"], t["ret"], t["val"], cfg)
+    loss.backward()
+    g_ref = torch.cat([p.grad.reshape(-1) for p in ps])
+    # sharded
+    sl = parallel.shard_slice(M, rank, world)
+    stats = parallel.global_adv_stats(t["adv"][sl])
+    a_all = t["adv"].double()
+    assert abs(float(stats[0]) - float(a_all.mean())) < 1e-6 and abs(float(stats[1]) - (float(a_all.std()) + 1e-8)) < 1e-6
+    ag = make_agent()
+    ps = [p.requires_grad_(True) for p in ag.parameters()]
+    adv_n = (t["adv"][sl] - stats[0]) / stats[1]
+    cfg_local = dict(cfg, norm_adv=False)
+    loss, _ = PO.ppo_minibatch_loss(ag, t["obs"][sl], t["act"][sl], t["logp"][sl], adv_n, t["ret"][sl], t["val"][sl], cfg_local)
+    (loss * (adv_n.numel() / M)).backward()       # mean over the local shard -> 1/M_global scaling
+    g = torch.cat([p.grad.reshape(-1) for p in ps])
+    parallel.allreduce_sum_(g)
+    assert float((g - g_ref).abs().max()) < 1e-6 * max(1.0, float(g_ref.abs().max())), float((g - g_ref).abs().max())
+    res["grad"] = True
+
+    # ---- 4. broadcast of the flat parameters from rank 0
+    flat = torch.full((10,), float(rank))
+    parallel.broadcast_(flat, src=0)
+    assert float(flat.sum()) == 0.0
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write(",".join(sorted(res)))
+    dist.destroy_process_group()
+
+
+def test_env_sharding_world2_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"ok{r}").read() == "cat,grad,rms"
+
+
+def test_shard_slices_cover_everything():
+    sys.path.insert(0, os.path.join(ROOT, "constraints-as-terminations_amd"))
+    from cat_envs import parallel
+    for n in (1, 7, 4096, 16385):
+        for w in (1, 2, 3, 8):
+            got = []
+            for r in range(w):
+                s = parallel.shard_slice(n, r, w)
+                got += list(range(n))[s]
+            assert got == list(range(n))
+    assert parallel.world_size() == 1 and not parallel.active()

@@ -1,0 +1,199 @@
+"""Host-side logic that needs no GPU: config surface, term parsing / error behaviour, curriculum,
+registry, CLI, checkpoint discovery, C oracle vs goldens."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import streams as S
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class _Env:
+    num_envs, device = 8, "cpu"
+    common_step_counter = 0
+    episode_length_buf = torch.ones(8, dtype=torch.long)
+
+
+def _cfg(**terms):
+    from cat_envs.shim import configclass
+    ns = {k: v for k, v in terms.items()}
+    return configclass(type("Cfg", (), ns))()
+
+
+def test_constraint_term_cfg_and_manager_parsing():
+    from cat_envs.tasks.utils.cat import ConstraintManager, ConstraintTermCfg
+    f = lambda env, limit: torch.zeros(env.num_envs)
+    cfg = {"a": ConstraintTermCfg(func=f, params={"limit": 1.0}, max_p=0.25),
+           "skip": None,
+           "b": ConstraintTermCfg(func=f, params={"limit": 2.0}, max_p=1)}
+    m = ConstraintManager(cfg, _Env())
+    assert m.active_terms == ["a", "b"]
+    assert m.get_term_cfg("b").max_p == 1
+    with pytest.raises(ValueError, match="not found"):
+        m.get_term_cfg("zzz")
+    with pytest.raises(ValueError, match="not found"):
+        m.set_term_cfg("zzz", cfg["a"])
+    new = ConstraintTermCfg(func=f, params={"limit": 1.0}, max_p=0.5)
+    m.set_term_cfg("a", new)
+    assert m.get_term_cfg("a") is new
+    assert "contains 2 active terms" in str(m) and "a" in str(m)
+    assert set(m._episode_sums) == {"a", "b"} and m._episode_sums["a"].shape == (8,)
+    # same exceptions as the reference's _prepare_terms (constraint_manager.py:248-258)
+    with pytest.raises(TypeError, match="is not ConstraintTermCfg"):
+        ConstraintManager({"a": object()}, _Env())
+    with pytest.raises(TypeError, match="must be float or int"):
+        ConstraintManager({"a": ConstraintTermCfg(func=f, params={"limit": 1.0}, max_p="0.1")}, _Env())
+    with pytest.raises(ValueError, match="mandatory parameters"):
+        ConstraintManager({"a": ConstraintTermCfg(func=f, params={}, max_p=0.1)}, _Env())
+    # no GPU: compute() must fail loudly instead of falling back
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.compute()
+
+
+def test_curriculum_matches_reference_table(golden):
+    from cat_envs.tasks.utils.cat import ConstraintManager, ConstraintTermCfg
+    from cat_envs.tasks.utils.cat.curriculums import modify_constraint_p
+    g = golden("curriculum")
+    env = _Env()
+    env.constraint_manager = ConstraintManager(
+        {"x": ConstraintTermCfg(func=lambda e: torch.zeros(8), params={}, max_p=0.25)}, env)
+    for i, init in enumerate(g["inits"]):
+        for j, step in enumerate(g["steps"]):
+            env.common_step_counter = int(step)
+            got = modify_constraint_p(env, None, "x", int(g["num_steps"]), float(init))
+            assert got == g["max_p"][i, j]
+            assert env.constraint_manager.get_term_cfg("x").max_p == got
+
+
+def test_task_registry_and_configs():
+    import cat_envs.tasks  # noqa: F401
+    from cat_envs.shim import load_cfg_from_registry, registry
+    assert "Isaac-Velocity-CaT-Flat-Solo12-v0" in registry and "Isaac-Velocity-CaT-Flat-Solo12-Play-v0" in registry
+    env_cfg = load_cfg_from_registry("Isaac-Velocity-CaT-Flat-Solo12-v0", "env_cfg_entry_point")
+    terms = env_cfg.constraints.__dict__
+    # reference ConstraintsCfg: 13 terms (cat_flat_env_cfg.py:259-355) with these max_p
+    assert list(terms) == [t[0] for t in S.CAT_TERMS_SOLO12]
+    assert [terms[k].max_p for k in terms] == S.CAT_MAXP_SOLO12
+    assert terms["joint_torque"].params["limit"] == 3.0 and terms["no_move"].params["joint_vel_limit"] == 4.0
+    assert len(env_cfg.curriculum.__dict__) == 8
+    assert env_cfg.scene.num_envs == 4096 and env_cfg.decimation == 4 and env_cfg.episode_length_s == 10.0
+    a = load_cfg_from_registry("Isaac-Velocity-CaT-Flat-Solo12-v0", "clean_rl_cfg_entry_point")
+    # reference clean_rl_ppo_cfg.py:12-34
+    assert (a.learning_rate, a.num_steps, a.num_iterations, a.gamma, a.gae_lambda) == (3e-4, 24, 2000, 0.99, 0.95)
+    assert (a.updates_epochs, a.minibatch_size, a.clip_coef, a.ent_coef, a.vf_coef) == (5, 16384, 0.2, 0.001, 2.0)
+    assert a.max_grad_norm == 1.0 and a.norm_adv and a.clip_vloss and a.anneal_lr and a.save_interval == 50
+    assert a.to_dict()["experiment_name"] == "solo12_flat" and a.load_checkpoint == "model_.*.pt"
+    play = load_cfg_from_registry("Isaac-Velocity-CaT-Flat-Solo12-Play-v0", "env_cfg_entry_point")
+    assert play.scene.num_envs == 50
+
+
+def test_scene_entity_resolution():
+    from cat_envs.shim import SceneEntityCfg
+    from cat_envs.tasks.utils.cat.cat_env import SOLO12_BODIES, SOLO12_JOINTS
+    import types
+    scene = {"robot": types.SimpleNamespace(joint_names=SOLO12_JOINTS, body_names=SOLO12_BODIES)}
+    c = SceneEntityCfg("robot", joint_names=[".*_HAA", ".*_HFE", ".*_KFE"])
+    c.resolve(scene)
+    assert c.joint_ids == slice(None)
+    c = SceneEntityCfg("robot", joint_names=["FL_HFE", "FR_HFE"])
+    c.resolve(scene)
+    assert c.joint_ids == [1, 4]
+    c = SceneEntityCfg("robot", body_names=["base_link", ".*_UPPER_LEG"])
+    c.resolve(scene)
+    assert c.body_ids == [0, 2, 6, 10, 14]
+    c = SceneEntityCfg("robot", body_names=".*_FOOT")
+    c.resolve(scene)
+    assert c.body_ids == [4, 8, 12, 16]
+    with pytest.raises(ValueError):
+        SceneEntityCfg("robot", joint_names=["nope"]).resolve(scene)
+
+
+def test_cli_surface(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "scripts", "clean_rl"))
+    import importlib
+    train = importlib.import_module("train")
+    play = importlib.import_module("play")
+    p = train.build_parser()
+    a, rest = p.parse_known_args(["--task", "T", "--num_envs", "64", "--seed", "7", "--num_iterations", "3",
+                                  "--experiment_name", "e", "--logger", "tensorboard", "--headless",
+                                  "--load_run", "r", "--checkpoint", "c.pt", "--log_project_name", "p",
+                                  "agent.minibatch_size=512", "--video_length", "10", "--video_interval", "5"])
+    assert (a.task, a.num_envs, a.seed, a.num_iterations, a.headless) == ("T", 64, 7, 3, True)
+    assert rest == ["agent.minibatch_size=512"]
+    import cli_args
+    import cat_envs.tasks  # noqa: F401
+    from cat_envs.shim import load_cfg_from_registry
+    cfg = cli_args.update_clean_rl_cfg(load_cfg_from_registry("Isaac-Velocity-CaT-Flat-Solo12-v0",
+                                                              "clean_rl_cfg_entry_point"), a)
+    assert (cfg.seed, cfg.load_run, cfg.load_checkpoint, cfg.logger) == (7, "r", "c.pt", "tensorboard")
+    train.apply_overrides({"agent": cfg}, rest)
+    assert cfg.minibatch_size == 512
+    # checkpoint discovery: latest run, highest iteration (reference naming model_<it>.pt)
+    for run, files in (("2026-01-01_00-00-00", ["model_49.pt", "model_99.pt"]), ("2026-02-01_00-00-00", ["model_49.pt", "model_149.pt", "model_99.pt"])):
+        os.makedirs(tmp_path / run)
+        for f in files:
+            (tmp_path / run / f).write_bytes(b"")
+    assert play.get_checkpoint_path(str(tmp_path), ".*", "model_.*.pt").endswith("2026-02-01_00-00-00/model_149.pt")
+
+
+def _c_oracle():
+    import __graft_entry__ as ge
+    ge._build_module().build_oracle_c()
+    return C.CDLL(os.path.join(ROOT, "oracle", "liboracle_c.so"))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.mark.parametrize("tag", ["small", "minp", "solo64"])
+def test_c_oracle_cat_step_vs_reference_golden(golden, tag):
+    lib = _c_oracle()
+    g = golden(f"cat_{tag}")
+    n, steps = int(g["n_envs"]), int(g["steps"])
+    terms = list(zip([str(x) for x in g["term_names"]], [int(w) for w in g["term_widths"]], [str(k) for k in g["term_kinds"]]))
+    stream = S.cat_stream(int(g["seed"]), n, terms, steps)
+    K, nt = sum(w for _, w, _ in terms), len(terms)
+    off = np.concatenate([[0], np.cumsum([w for _, w, _ in terms])]).astype(np.int32)
+    rm, prob = np.zeros(K, np.float32), np.zeros(n, np.float32)
+    viol, eprob = np.zeros((nt, n), np.float32), np.zeros((nt, n), np.float32)
+    tau, min_p = float(g["tau"]), float(g["min_p"])
+    reset_at = set(int(x) for x in g["reset_at"])
+    f32 = lambda x: C.c_float(x)
+    for t in range(steps):
+        cstr = np.ascontiguousarray(np.concatenate(
+            [np.asarray(stream[t][nm]).astype(np.float32).reshape(n, -1) for nm, _, _ in terms], 1))
+        dp = np.array([C.c_float(p - min_p).value for p in g["max_p"][t]], np.float32)
+        lib.cat_step_oracle(_fp(cstr), C.c_int64(n), K, _fp(off), nt, _fp(dp), f32(min_p), f32(tau), f32(1.0 - tau),
+                            int(t == 0), _fp(rm), None, None, _fp(prob), None, _fp(viol), _fp(eprob), None)
+        np.testing.assert_array_equal(prob, g["cstr_prob"][t])
+        np.testing.assert_array_equal(rm, g["running_maxes"][t])
+        if t in reset_at:
+            ids = g[f"reset{t}_ids"]
+            viol[:, ids] = 0
+            eprob[:, ids] = 0
+    np.testing.assert_array_equal(viol, g["episode_sums"])
+    np.testing.assert_array_equal(eprob, g["cstr_mean_values"])
+
+
+def test_c_oracle_gae_vs_reference_ppo_run(golden):
+    lib = _c_oracle()
+    g = golden("ppo_64x24")
+    N, T = 64, 24
+    s = S.env_stream(int(g["seed"]), T * 3, N, 45)
+    dones = np.ascontiguousarray(np.concatenate([np.zeros((1, N), np.float32), s["dones"][:T - 1]]))
+    tdones = np.ascontiguousarray(np.concatenate([np.zeros((1, N), np.float32), s["timeouts"][:T - 1].astype(np.float32)]))
+    rew, val = np.ascontiguousarray(s["reward"][:T]), np.ascontiguousarray(g["it0_values"])
+    nv = np.ascontiguousarray(g["it0_next_value"])
+    nd, ntd = np.ascontiguousarray(s["dones"][T - 1]), np.ascontiguousarray(s["timeouts"][T - 1].astype(np.float32))
+    adv, ret = np.zeros((T, N), np.float32), np.zeros((T, N), np.float32)
+    lib.gae_oracle(_fp(rew), _fp(val), _fp(dones), _fp(tdones), _fp(nv), _fp(nd), _fp(ntd), C.c_float(0.99),
+                   C.c_float(0.99 * 0.95), _fp(adv), _fp(ret), T, C.c_int64(N))
+    np.testing.assert_array_equal(adv, g["it0_advantages"])
+    np.testing.assert_array_equal(ret, g["it0_returns"])
