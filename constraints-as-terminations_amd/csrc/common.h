@@ -15,6 +15,12 @@ struct catppo_ctx {
   int n_cu = 256;
   void* ws = nullptr;        // generic workspace (device)
   uint64_t ws_bytes = 0;
+  // side stream + events: the weight-gradient GEMMs of the backward pass run beside the
+  // data-gradient chain (fork/join around catppo_ppo_minibatch_grad, capturable in a hipGraph)
+  hipStream_t side = nullptr;
+  bool use_side = false;     // CATPPO_SIDE_STREAM=1 forks the weight-gradient GEMMs (measured slower)
+  hipEvent_t ev_fork[CATPPO_MAX_HIDDEN + 1] = {};
+  hipEvent_t ev_join = nullptr;
   char err[512] = {0};
 };
 

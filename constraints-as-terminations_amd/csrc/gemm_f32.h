@@ -28,8 +28,7 @@ namespace gemm {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 16;
-constexpr int KC_STRIDE = BK + 4;  // floats, K-contig LDS row stride
+constexpr int BK = 16;             // default contraction slab; kernels take it as the BKT template parameter
 
 enum Epilogue {
   EPI_BIAS_ELU = 0,  // C = elu(acc + bias[j])                       forward hidden layer
@@ -56,10 +55,19 @@ struct Params {
   int64_t c_split_stride;  // floats between consecutive split outputs
 };
 
-__device__ __forceinline__ float elu_f(float z) { return z > 0.0f ? z : (expf(z) - 1.0f); }
+// ELU(alpha=1).  exp through the hardware exp2 (v_exp_f32, ~1 ulp on the (0,1] range that matters
+// here): |error| < 2e-7 absolute on the activation, far inside the 1e-5 parity budget, and 10x
+// fewer VALU instructions than expf in an epilogue that runs 64 of them per lane.
+__device__ __forceinline__ float elu_f(float z) {
+  const float e = __builtin_amdgcn_exp2f(z * 1.44269504088896340736f) - 1.0f;
+  return z > 0.0f ? z : e;
+}
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
+  constexpr int BK = BKT;                      // shadows gemm::BK inside the kernel
+  constexpr int KC_STRIDE = BK + 4;            // floats, K-contig LDS row stride (80 B / 144 B: conflict-free b128)
+  constexpr int KQ = BK / 4;                   // float4 per K-contig row of a slab
   constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
   constexpr int WM = BM / 2, WN = BN / 2;    // wave tile
   constexpr int A_TILE = A_KC ? BM * KC_STRIDE : BK * BM;
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
       const int f = tid + q * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (A_KC) {
-        const int r = f >> 2, kq = f & 3;  // 4 float4 per 16-wide row
+        const int r = f / KQ, kq = f % KQ;
         const int gi = i0 + r;
         if (gi < p.I) v = *reinterpret_cast<const float4*>(op.A + (int64_t)gi * p.lda + k0 + 4 * kq);
       } else {
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
       const int f = tid + q * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (B_KC) {
-        const int r = f >> 2, kq = f & 3;
+        const int r = f / KQ, kq = f % KQ;
         const int gj = j0 + r;
         if (gj < p.J) v = *reinterpret_cast<const float4*>(op.B + (int64_t)gj * p.ldb + k0 + 4 * kq);
       } else {
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
     for (int q = 0; q < A_LD4; ++q) {
       const int f = tid + q * 256;
       if (A_KC) {
-        const int r = f >> 2, kq = f & 3;
+        const int r = f / KQ, kq = f % KQ;
         *reinterpret_cast<float4*>(a + r * KC_STRIDE + 4 * kq) = ra[q];
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
     for (int q = 0; q < B_LD4; ++q) {
       const int f = tid + q * 256;
       if (B_KC) {
-        const int r = f >> 2, kq = f & 3;
+        const int r = f / KQ, kq = f % KQ;
         *reinterpret_cast<float4*>(b + r * KC_STRIDE + 4 * kq) = rb[q];
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
@@ -183,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
     }
 
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
+    for (int blk = 0; blk < BK / 8; ++blk) {
       float af[TM][4], bf[TN][4];
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
@@ -236,11 +244,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
         if (gi < p.I && gj < p.J) {
           float v = acc[tm][tn][r];
           if (EPI == EPI_BIAS_ELU) {
+#ifdef GEMM_PROBE_NOELU
+            v = v + bias;
+#else
             v = elu_f(v + bias);
+#endif
           } else if (EPI == EPI_MUL_DELU) {
             const float hact = op.aux[(int64_t)gi * p.ldaux + gj];
             v = v * (hact > 0.0f ? 1.0f : hact + 1.0f);  // elu'(z) = 1 (z>0) | exp(z) = elu(z)+1
           }
+#ifdef GEMM_PROBE_NOSTORE
+          if (v == 12345.678f)
+#endif
           Cout[(int64_t)gi * p.ldc + gj] = v;
         }
       }
@@ -251,10 +266,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, bool A_KC, bool B_KC, int BKT = BK>
 constexpr size_t smem_bytes() {
   return sizeof(float) * 2 *
-         ((A_KC ? BM * KC_STRIDE : BK * BM) + (B_KC ? BN * KC_STRIDE : BK * BN));
+         ((A_KC ? BM * (BKT + 4) : BKT * BM) + (B_KC ? BN * (BKT + 4) : BKT * BN));
 }
 
 }  // namespace gemm

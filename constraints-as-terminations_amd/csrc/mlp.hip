@@ -130,11 +130,17 @@ void launch_gemm(const Params& p, hipStream_t s) {
   gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI><<<grid, dim3(256), lds, s>>>(p);
 }
 
-// pick 128x128 tiles when they already give >= 1.5 workgroups per CU, else 64x64
+// Tile choice from tools/gemm_probe on MI355X (M=16384, both nets per launch): 128x128 pays only when
+// the contraction is long enough to amortise its heavier epilogue and there are >= 1.5 workgroups per
+// CU; the data-gradient form (aux read + store epilogue) is always better with 64x64 tiles.
 template <bool A_KC, bool B_KC, int EPI>
 void launch_gemm_auto(const Params& p, hipStream_t s) {
   const int64_t big = (int64_t)((p.I + 127) / 128) * ((p.J + 127) / 128) * p.nets * p.splits;
-  if (big >= 384 && p.I >= 128 && p.J >= 128)
+  const int kc = EPI == gemm::EPI_PARTIAL ? p.kc_per_split : p.Kc;
+  // weight gradients pick their split count to fill the chip, so only the shape matters there
+  const bool use_big = EPI != gemm::EPI_MUL_DELU && p.I >= 128 && p.J >= 128 && kc >= 256 &&
+                       (EPI == gemm::EPI_PARTIAL || big >= 384);
+  if (use_big)
     launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s);
   else
     launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s);
@@ -176,9 +182,48 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// CPL consecutive floats per lane as ONE store instruction (rows are 16-B aligned: HL % 64 == 0)
+template <int CPL>
+__device__ __forceinline__ void store_vec(float* p, const float (&v)[CPL]) {
+  if constexpr (CPL == 1) {
+    p[0] = v[0];
+  } else if constexpr (CPL == 2) {
+    *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q)
+      reinterpret_cast<float4*>(p)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+}
+
+// Sixteen per-lane partial values -> their 64-lane totals with 17 cross-lane exchanges instead of
+// 16 x 6: every butterfly step halves the number of live values (the lane keeps the half selected by
+// its own bit and hands the other half to its partner).  Afterwards the total of value j sits in the
+// four lanes l with slot(l) == j, slot(l) = 8*bit5 + 4*bit4 + 2*bit3 + bit2.
+__device__ __forceinline__ float reduce16(float (&v)[16], int lane) {
+  float a[8], b[4], c[2];
+  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = (h5 ? v[j + 8] : v[j]) + __shfl_xor(h5 ? v[j] : v[j + 8], 32, 64);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = (h4 ? a[j + 4] : a[j]) + __shfl_xor(h4 ? a[j] : a[j + 4], 16, 64);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) c[j] = (h3 ? b[j + 2] : b[j]) + __shfl_xor(h3 ? b[j] : b[j + 2], 8, 64);
+  float s = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 1, 64);
+  return s;
+}
+__host__ __device__ constexpr int slot_lane(int j) {   // first lane holding the total of value j
+  return ((j >> 3) & 1) << 5 | ((j >> 2) & 1) << 4 | ((j >> 1) & 1) << 3 | (j & 1) << 2;
+}
+__device__ __forceinline__ float lane_bcast(float x, int src_lane) {   // src_lane is a compile-time constant
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
+}
+
 // ------------------------------------------------------------------------------- rollout head
-// one wave per row: lane owns CPL = HL/64 columns of the last hidden activation; after the A+1
-// wave-wide dot products lane k (< A) owns action dimension k (mean, sample, log-prob term).
+// one wave per row: lane owns CPL = HL/64 columns of the last hidden activation; the A+1 dot products
+// of a row are reduced together (reduce16), after which the lanes of slot k own action dimension k.
 template <int CPL>
 __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__ Hc, const float* __restrict__ Ha,
                                                        const float* __restrict__ W4c, const float* __restrict__ b4c,
@@ -189,45 +234,56 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
                                                        float* __restrict__ action, float* __restrict__ logprob,
                                                        float* __restrict__ value) {
   constexpr int HL = CPL * 64;
-  extern __shared__ float lds[];   // [A*HL] actor head weights
+  constexpr int VS = 15;
+  extern __shared__ float lds[];   // [16*HL] actor head weights, rows >= A zero
   const int lane = threadIdx.x & 63;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * 4;
-  for (int o = threadIdx.x; o < A * HL; o += 256) lds[o] = W4a[o];
+  for (int o = threadIdx.x; o < 16 * HL; o += 256) lds[o] = (W4a != nullptr && o < A * HL) ? W4a[o] : 0.0f;
   __syncthreads();
   float wc[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) wc[c] = W4c[lane * CPL + c];
   const float bc = b4c[0];
-  const bool mine = lane < A;
-  const float sd = mine ? expf(logstd[lane]) : 1.0f;
+  const int slot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+  const bool mine = slot < A;
+  const float sd = mine ? expf(logstd[slot]) : 1.0f;
   const float var = sd * sd, lsd = logf(sd);
-  const float ba = mine ? b4a[lane] : 0.0f;
+  const float ba = mine ? b4a[slot] : 0.0f;
   for (int64_t i = wave_id; i < M; i += n_waves) {
-    float dot = 0.0f;
+    float part[16];
+    float dc = 0.0f;
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) dot = fmaf(Hc[i * HL + lane * CPL + c], wc[c], dot);
-    const float v = wave_sum(dot) + bc;
+    for (int c = 0; c < CPL; ++c) dc = fmaf(Hc[i * HL + lane * CPL + c], wc[c], dc);
+    part[VS] = dc;
     if (Ha != nullptr) {
       float ha[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) ha[c] = Ha[i * HL + lane * CPL + c];
-      float mu = 0.0f;
-      for (int k = 0; k < A; ++k) {
+#pragma unroll
+      for (int k = 0; k < VS; ++k) {
         float d = 0.0f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], lds[k * HL + lane * CPL + c], d);
-        d = wave_sum(d);
-        if (lane == k) mu = d;
+        part[k] = d;
       }
-      mu += ba;
+    } else {
+#pragma unroll
+      for (int k = 0; k < VS; ++k) part[k] = 0.0f;
+    }
+    const float tot = reduce16(part, lane);
+    const float v = lane_bcast(tot, slot_lane(VS)) + bc;
+    if (Ha != nullptr) {
+      const float mu = tot + ba;
       float a = mu;
-      if (mine && given != nullptr) a = given[i * A + lane];
-      else if (mine && eps != nullptr) a = mu + sd * eps[i * A + lane];   // Normal.sample(): loc + scale*N(0,1)
+      if (mine && given != nullptr) a = given[i * A + slot];
+      else if (mine && eps != nullptr) a = mu + sd * eps[i * A + slot];   // Normal.sample(): loc + scale*N(0,1)
       const float diff = a - mu;
       const float term = mine ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f;
-      const float lp = wave_sum(term);
-      if (mine) action[i * A + lane] = a;
+      float lp = 0.0f;
+#pragma unroll
+      for (int k = 0; k < VS; ++k) lp += lane_bcast(term, slot_lane(k));
+      if (mine && (lane & 3) == 0) action[i * A + slot] = a;
       if (lane == 0) logprob[i] = lp;
     }
     if (lane == 0) value[i] = v;
@@ -294,50 +350,41 @@ struct HeadArgs {
   catppo_ppo_hparams hp;
 };
 
-// Sixteen per-lane partial values -> their 64-lane totals with 17 cross-lane exchanges instead of
-// 16 x 6: every butterfly step halves the number of live values (the lane keeps the half selected by
-// its own bit and hands the other half to its partner).  Afterwards the total of value j sits in the
-// four lanes l with slot(l) == j, slot(l) = 8*bit5 + 4*bit4 + 2*bit3 + bit2.
-__device__ __forceinline__ float reduce16(float (&v)[16], int lane) {
-  float a[8], b[4], c[2];
-  const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) a[j] = (h5 ? v[j + 8] : v[j]) + __shfl_xor(h5 ? v[j] : v[j + 8], 32, 64);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) b[j] = (h4 ? a[j + 4] : a[j]) + __shfl_xor(h4 ? a[j] : a[j + 4], 16, 64);
-#pragma unroll
-  for (int j = 0; j < 2; ++j) c[j] = (h3 ? b[j + 2] : b[j]) + __shfl_xor(h3 ? b[j] : b[j + 2], 8, 64);
-  float s = (h2 ? c[1] : c[0]) + __shfl_xor(h2 ? c[0] : c[1], 4, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 1, 64);
-  return s;
-}
-__host__ __device__ constexpr int slot_lane(int j) {   // first lane holding the total of value j
-  return ((j >> 3) & 1) << 5 | ((j >> 2) & 1) << 4 | ((j >> 1) & 1) << 3 | (j & 1) << 2;
-}
-__device__ __forceinline__ float lane_bcast(float x, int src_lane) {   // src_lane is a compile-time constant
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
-}
-
-static_assert(kHeadRowsPerBlock == 32, "8 waves x 4 rows");
+static_assert(kHeadRowsPerBlock == 32, "8 waves x 4 rows per tile");
 constexpr int kHeadWaves = 8;        // waves per block
-constexpr int kHeadRowsPerWave = 4;  // => 32 rows per block, 512 blocks for a 16384-sample minibatch
+constexpr int kHeadRowsPerWave = 4;  // rows of a tile handled by one wave
+constexpr int kHeadMaxBlocks = 256;  // = number of weight-gradient partials folded afterwards
 
-// AM = compile-time bound on the action dimension (register arrays and unrolled loops)
-template <int CPL, int AM>
-__global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 2 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
+// Heads + PPO loss + backward through the heads, one tile of 32 minibatch rows at a time:
+//   phase 1 (wave per row)  last-hidden rows -> registers AND an LDS tile; A+1 dot products per row
+//           (batched 16-value butterfly), log-prob, clipped losses, analytic d loss/d mu, d loss/d v;
+//           dZ of the last hidden layer is stored; the per-row head gradients go to an LDS [32][16] tile
+//   phase 2 (thread per weight column)  dW4 += G^T . H over the 32 rows of the tile from LDS; accumulators
+//           stay in registers across the tiles of the block => ONE partial per block, no per-wave
+//           reduction rounds
+template <int CPL>
+__global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
   constexpr int HL = CPL * 64;
-  // LDS: [A*HL] actor head weights | [(A+1)*HL] weight-grad accumulation | [NS] scalars
-  extern __shared__ float lds[];
+  constexpr int NT = kHeadWaves * 64;
+  constexpr int NG = NT / HL >= 1 ? NT / HL : 1;       // phase-2 thread groups (HL <= 512)
+  constexpr int KPG = 16 / NG;                         // head outputs per group (16 slots)
+  constexpr int TR = kHeadRowsPerBlock;
+  constexpr int VS = 15;                               // slot of the critic output; actions use slots 0..A-1
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float s_adv[2];
   const int A = g.A;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NS = 2 * A + 1 + kHeadDiag;
-  float* s_wa = lds;
-  float* lw = lds + A * HL;               // rows 0..A-1 = dW4a, row A = dW4c
-  float* ls = lw + (A + 1) * HL;          // db4a[A], db4c, dlogstd[A], diag[8]
+  // every loop below runs over the 16 compile-time slots; unused slots carry zeros (weights, gradients)
+  // so there is no data-dependent control flow inside the row loop
+  float* s_wa = lds;                       // [16*HL]  actor head weights, rows >= A zero
+  float* sHa = s_wa + 16 * HL;             // [TR*HL]  actor last-hidden tile
+  float* sHc = sHa + TR * HL;              // [TR*HL]  critic last-hidden tile
+  float* sG = sHc + TR * HL;               // [TR*16]  per-row head gradients: d mu_k (k<A), 0, ..., d v at VS
+  float* ls = sG + TR * 16;                // [NS]     scalars: db4a[A], db4c, dlogstd[A], diag[8]
 
-  for (int o = threadIdx.x; o < A * HL; o += kHeadWaves * 64) s_wa[o] = g.W4a[o];
+  for (int o = tid; o < 16 * HL; o += NT) s_wa[o] = o < A * HL ? g.W4a[o] : 0.0f;
+  for (int o = tid; o < TR * 16; o += NT) sG[o] = 0.0f;
   // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
   if (wave == 0) {
     if (g.hp.norm_adv && g.adv_stats == nullptr) {
@@ -365,8 +412,10 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 2 ? 4 : 2)) void head_loss
   const float adv_mean = s_adv[0], adv_den = s_adv[1];
   const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
   const float vden = sqrtf(g.vrms_var[0] + 1e-8f), vmean = g.vrms_mean[0];
+  const bool norm_adv = g.hp.norm_adv != 0, clip_vloss = g.hp.clip_vloss != 0;
+  const float ent_coef_m = g.hp.ent_coef * invM, vf_half = g.hp.vf_coef * 0.5f;
 
-  // after reduce16 the lanes with slot == k own action dimension k; slot A carries the critic output
+  // after reduce16 the four lanes with slot(lane) == k hold the total of value k
   const int slot = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
   const bool mine = slot < A;
   const bool leader = mine && (lane & 3) == 0;    // one lane per action dim accumulates / publishes
@@ -374,151 +423,153 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 2 ? 4 : 2)) void head_loss
   const float var = sd * sd, lsd = logf(sd);
   const float ba = mine ? g.b4a[slot] : 0.0f;
   float ent_row = 0.0f;                           // entropy is state independent
+  {
+    const float e = mine ? kEntConst + lsd : 0.0f;
 #pragma unroll
-  for (int k = 0; k < AM; ++k)
-    if (k < A) ent_row += lane_bcast(kEntConst + lsd, slot_lane(k));
-  float gba = 0.0f, gls = 0.0f;                   // per action dim accumulators (leader lanes)
-  float wc[CPL], gwc[CPL];
-#pragma unroll
-  for (int c = 0; c < CPL; ++c) wc[c] = g.W4c[lane * CPL + c], gwc[c] = 0.0f;
-  float gwa[AM][CPL];
-#pragma unroll
-  for (int k = 0; k < AM; ++k)
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) gwa[k][c] = 0.0f;
-  float gbc = 0.0f;
+    for (int k = 0; k < VS; ++k) ent_row += lane_bcast(e, slot_lane(k));
+  }
+  float gls = 0.0f;                               // d loss / d logstd_k (leader lanes)
   float d_pg = 0.0f, d_v = 0.0f, d_ent = 0.0f, d_kl = 0.0f, d_okl = 0.0f, d_cf = 0.0f;
+  float wc[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) wc[c] = g.W4c[lane * CPL + c];
   const float bc = g.b4c[0];
 
-  const int64_t r0 = ((int64_t)blockIdx.x * kHeadWaves + wave) * kHeadRowsPerWave;
-  for (int rr = 0; rr < kHeadRowsPerWave; ++rr) {
-    const int64_t i = r0 + rr;
-    if (i >= g.M) break;   // wave-uniform
-    float hc[CPL], ha[CPL];
-    float part[16];
+  // phase-2 ownership: weight column c2, slots [k0, k0+KPG)
+  const int c2 = tid % HL, grp = tid / HL, k0 = grp * KPG;
+  float acc[KPG];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      hc[c] = g.Hc[i * HL + lane * CPL + c];
-      ha[c] = g.Ha[i * HL + lane * CPL + c];
-    }
+  for (int kk = 0; kk < KPG; ++kk) acc[kk] = 0.0f;
+  float accb = 0.0f;                              // bias gradients: threads 0..15 (one per slot)
+
+  const int64_t n_tiles = (g.M + TR - 1) / TR;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * TR;
+    const int rows = (int)((g.M - row0) < TR ? (g.M - row0) : TR);
+    // ------------------------------------------------------------------ phase 1
+    for (int rr = 0; rr < kHeadRowsPerWave; ++rr) {
+      const int r = wave * kHeadRowsPerWave + rr;
+      if (r >= rows) break;                        // wave-uniform
+      const int64_t i = row0 + r;
+      float hc[CPL], ha[CPL], part[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float d = 0.0f;
-      if (k < A) {
+      for (int c = 0; c < CPL; ++c) {
+        hc[c] = g.Hc[i * HL + lane * CPL + c];
+        ha[c] = g.Ha[i * HL + lane * CPL + c];
+      }
+      const float a_taken = mine ? g.act[i * A + slot] : 0.0f;
+      const float oldlogp = g.oldlogp[i], adv_raw = g.adv[i], R = g.ret_n[i], Vo = g.val_n[i];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        sHc[r * HL + lane * CPL + c] = hc[c];
+        sHa[r * HL + lane * CPL + c] = ha[c];
+      }
+#pragma unroll
+      for (int k = 0; k < VS; ++k) {
+        float d = 0.0f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], s_wa[k * HL + lane * CPL + c], d);
-      } else if (k == A) {
+        part[k] = d;
+      }
+      {
+        float d = 0.0f;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) d = fmaf(hc[c], wc[c], d);
+        part[VS] = d;
       }
-      part[k] = d;
-    }
-    const float tot = reduce16(part, lane);       // lane with slot k: mu_k (k<A) or the critic output (k==A)
-    const float mu = tot + ba;
-    float v = 0.0f;
+      const float tot = reduce16(part, lane);     // lanes of slot k: mu_k (k<A) / critic output (slot VS)
+      const float mu = tot + ba;
+      const float v = lane_bcast(tot, slot_lane(VS)) + bc;
+
+      // ---- log-prob of the taken action
+      const float diff = mine ? a_taken - mu : 0.0f;
+      const float term = mine ? -(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi : 0.0f;
+      float newlogp = 0.0f;
 #pragma unroll
-    for (int k = 0; k <= AM; ++k)
-      if (k == A) v = lane_bcast(tot, slot_lane(k < 16 ? k : 15)) + bc;
+      for (int k = 0; k < VS; ++k) newlogp += lane_bcast(term, slot_lane(k));
+      const float logratio = newlogp - oldlogp;
+      const float ratio = expf(logratio);
+      d_okl += -logratio;
+      d_kl += (ratio - 1.0f) - logratio;
+      d_cf += fabsf(ratio - 1.0f) > clipc ? 1.0f : 0.0f;
 
-    // ---- log-prob of the taken action
-    const float diff = mine ? g.act[i * A + slot] - mu : 0.0f;
-    const float term = -(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi;
-    float newlogp = 0.0f;
-#pragma unroll
-    for (int k = 0; k < AM; ++k)
-      if (k < A) newlogp += lane_bcast(term, slot_lane(k));
-    const float logratio = newlogp - g.oldlogp[i];
-    const float ratio = expf(logratio);
-    d_okl += -logratio;
-    d_kl += (ratio - 1.0f) - logratio;
-    d_cf += fabsf(ratio - 1.0f) > clipc ? 1.0f : 0.0f;
+      const float adv = norm_adv ? (adv_raw - adv_mean) / adv_den : adv_raw;
+      const float rc = ratio < 1.0f - clipc ? 1.0f - clipc : (ratio > 1.0f + clipc ? 1.0f + clipc : ratio);
+      const float pg1 = -adv * ratio, pg2 = -adv * rc;
+      const bool inside = ratio >= 1.0f - clipc && ratio <= 1.0f + clipc;
+      // d max(pg1,pg2) / d ratio   (torch.max splits ties 1/2 : 1/2; clamp passes gradient inside only)
+      const float dr_tie = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);
+      const float dr = pg1 > pg2 ? -adv : (pg1 < pg2 ? (inside ? -adv : 0.0f) : dr_tie);
+      d_pg += pg1 > pg2 ? pg1 : pg2;
+      const float g_logp = dr * ratio * invM;      // d loss / d newlogprob_i
 
-    float adv = g.adv[i];
-    if (g.hp.norm_adv) adv = (adv - adv_mean) / adv_den;
-    const float rc = ratio < 1.0f - clipc ? 1.0f - clipc : (ratio > 1.0f + clipc ? 1.0f + clipc : ratio);
-    const float pg1 = -adv * ratio, pg2 = -adv * rc;
-    const bool inside = ratio >= 1.0f - clipc && ratio <= 1.0f + clipc;
-    float dr;   // d max(pg1,pg2) / d ratio   (torch.max splits ties 1/2 : 1/2)
-    if (pg1 > pg2) dr = -adv;
-    else if (pg1 < pg2) dr = inside ? -adv : 0.0f;
-    else dr = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);
-    d_pg += pg1 > pg2 ? pg1 : pg2;
-    const float g_logp = dr * ratio * invM;      // d loss / d newlogprob_i
-
-    // ---- value head loss
-    const float nv = (v - vmean) / vden;         // value_rms(newvalue, update=False)
-    const float R = g.ret_n[i];
-    const float e1 = nv - R;
-    float vl = e1 * e1, dnv = 2.0f * e1;
-    if (g.hp.clip_vloss) {
-      const float Vo = g.val_n[i];
+      // ---- value head loss
+      const float nv = (v - vmean) / vden;         // value_rms(newvalue, update=False)
+      const float e1 = nv - R;
+      const float vl1 = e1 * e1;
       const float dl = nv - Vo;
       const float cl = dl < -clipc ? -clipc : (dl > clipc ? clipc : dl);
       const float e2 = (Vo + cl) - R;
       const float vl2 = e2 * e2;
       const bool in2 = dl >= -clipc && dl <= clipc;
-      if (vl > vl2) dnv = 2.0f * e1;
-      else if (vl < vl2) dnv = in2 ? 2.0f * e2 : 0.0f;
-      else dnv = e1 + (in2 ? e2 : 0.0f);
-      vl = vl > vl2 ? vl : vl2;
-    }
-    d_v += 0.5f * vl;
-    d_ent += ent_row;
-    const float g_v = g.hp.vf_coef * 0.5f * dnv * invM / vden;   // d loss / d v_i
+      const float dnv_c = vl1 > vl2 ? 2.0f * e1 : (vl1 < vl2 ? (in2 ? 2.0f * e2 : 0.0f) : e1 + (in2 ? e2 : 0.0f));
+      const float vl = clip_vloss ? (vl1 > vl2 ? vl1 : vl2) : vl1;
+      const float dnv = clip_vloss ? dnv_c : 2.0f * e1;
+      d_v += 0.5f * vl;
+      d_ent += ent_row;
+      const float g_v = vf_half * dnv * invM / vden;   // d loss / d v_i
 
-    // ---- backward through the heads
-    const float gm = mine ? g_logp * diff / var : 0.0f;           // d loss / d mu_ik   (lanes of slot k)
-    if (leader) {
-      gls += g_logp * (diff * diff / var - 1.0f) - g.hp.ent_coef * invM;
-      gba += gm;
-    }
-    float dha[CPL];
+      // ---- backward through the heads
+      const float gm = mine ? g_logp * diff / var : 0.0f;           // d loss / d mu_ik   (lanes of slot k)
+      if (leader) {
+        gls += g_logp * (diff * diff / var - 1.0f) - ent_coef_m;
+        sG[r * 16 + slot] = gm;
+      }
+      if (lane == 63) sG[r * 16 + VS] = g_v;         // lane 63 has slot 15 = VS
+      float dha[CPL];
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) dha[c] = 0.0f;
+      for (int c = 0; c < CPL; ++c) dha[c] = 0.0f;
 #pragma unroll
-    for (int k = 0; k < AM; ++k) {
-      if (k < A) {
+      for (int k = 0; k < VS; ++k) {
         const float gmk = lane_bcast(gm, slot_lane(k));
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) {
-          gwa[k][c] = fmaf(gmk, ha[c], gwa[k][c]);
-          dha[c] = fmaf(gmk, s_wa[k * HL + lane * CPL + c], dha[c]);
-        }
+        for (int c = 0; c < CPL; ++c) dha[c] = fmaf(gmk, s_wa[k * HL + lane * CPL + c], dha[c]);
       }
-    }
-    gbc += g_v;
-#pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-      gwc[c] = fmaf(g_v, hc[c], gwc[c]);
-      const float dhc = g_v * wc[c];
-      g.dZa[i * HL + lane * CPL + c] = dha[c] * (ha[c] > 0.0f ? 1.0f : ha[c] + 1.0f);
-      g.dZc[i * HL + lane * CPL + c] = dhc * (hc[c] > 0.0f ? 1.0f : hc[c] + 1.0f);
-    }
-  }
-
-  // ---- block reduction in fixed wave order (deterministic), then one partial per block
-  for (int w = 0; w < kHeadWaves; ++w) {
-    if (wave == w) {
-#pragma unroll
-      for (int k = 0; k < AM; ++k)
-        if (k < A) {
-#pragma unroll
-          for (int c = 0; c < CPL; ++c) {
-            const int o = k * HL + lane * CPL + c;
-            lw[o] = w == 0 ? gwa[k][c] : lw[o] + gwa[k][c];
-          }
-        }
+      float oa[CPL], oc[CPL];
 #pragma unroll
       for (int c = 0; c < CPL; ++c) {
-        const int o = A * HL + lane * CPL + c;
-        lw[o] = w == 0 ? gwc[c] : lw[o] + gwc[c];
+        oa[c] = dha[c] * (ha[c] > 0.0f ? 1.0f : ha[c] + 1.0f);
+        oc[c] = (g_v * wc[c]) * (hc[c] > 0.0f ? 1.0f : hc[c] + 1.0f);
       }
-      if (leader) {
-        ls[slot] = w == 0 ? gba : ls[slot] + gba;
-        ls[A + 1 + slot] = w == 0 ? gls : ls[A + 1 + slot] + gls;
-      }
-      if (lane == 63) {   // lane 63 (slot 15) never leads an action dim: it carries the uniform scalars
-        ls[A] = w == 0 ? gbc : ls[A] + gbc;
+      store_vec<CPL>(g.dZa + i * HL + lane * CPL, oa);
+      store_vec<CPL>(g.dZc + i * HL + lane * CPL, oc);
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ phase 2: dW4 += G^T . H
+    for (int r = 0; r < rows; ++r) {
+      const float ha2 = sHa[r * HL + c2], hc2 = sHc[r * HL + c2];
+#pragma unroll
+      for (int kk = 0; kk < KPG; ++kk)
+        acc[kk] = fmaf(sG[r * 16 + k0 + kk], (k0 + kk) == VS ? hc2 : ha2, acc[kk]);
+    }
+    if (tid < 16) {
+      for (int r = 0; r < rows; ++r) accb += sG[r * 16 + tid];
+    }
+    __syncthreads();
+  }
+
+  // ---- per-block partials: weight gradients straight from the phase-2 registers, scalars through LDS
+  float* pw = g.part_w + (int64_t)blockIdx.x * (A + 1) * HL;   // rows 0..A-1 = dW4a, row A = dW4c
+#pragma unroll
+  for (int kk = 0; kk < KPG; ++kk) {
+    const int k = k0 + kk;
+    if (k < A) pw[k * HL + c2] = acc[kk];
+    else if (k == VS) pw[A * HL + c2] = acc[kk];
+  }
+  for (int w = 0; w < kHeadWaves; ++w) {           // fixed wave order => deterministic
+    if (wave == w) {
+      if (leader) ls[A + 1 + slot] = w == 0 ? gls : ls[A + 1 + slot] + gls;
+      if (lane == 63) {
         float* dg = ls + 2 * A + 1;
         const float vals[kHeadDiag] = {d_pg, d_v, d_ent, 0.0f, d_kl, d_okl, d_cf, 0.0f};
 #pragma unroll
@@ -527,10 +578,11 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 2 ? 4 : 2)) void head_loss
     }
     __syncthreads();
   }
-  float* pw = g.part_w + (int64_t)blockIdx.x * (A + 1) * HL;
-  for (int o = threadIdx.x; o < (A + 1) * HL; o += kHeadWaves * 64) pw[o] = lw[o];
+  if (tid < A) ls[tid] = accb;                     // db4a[0..A-1]
+  if (tid == VS) ls[A] = accb;                     // db4c
+  __syncthreads();
   float* ps = g.part_s + (int64_t)blockIdx.x * NS;
-  for (int o = threadIdx.x; o < NS; o += kHeadWaves * 64) ps[o] = ls[o];
+  for (int o = tid; o < NS; o += NT) ps[o] = ls[o];
 }
 
 // ------------------------------------------------------------------------------- segmented partial reduction
@@ -554,11 +606,12 @@ struct SegTable {
 // block = EL elements x G part-groups (EL*G = 256).  Thread (e,g) adds parts g, g+G, ... in order, the G
 // group sums are then combined in LDS in fixed order => deterministic, and at most n_parts/G
 // dependent adds per thread with the loads issued ahead (unrolled).
-template <int G>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
-  constexpr int EL = 256 / G;
   __shared__ float sm[256];
   const Seg sg = t.s[blockIdx.y];
+  // few wide partials (split-K): 4 part groups x 64 elements (256-B rows); many narrow ones (head): 16 x 16
+  const int G = sg.n_parts >= 128 ? 16 : 4;
+  const int EL = 256 / G;
   const int el = threadIdx.x % EL, g = threadIdx.x / EL;
   for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < sg.count; e0 += (int64_t)gridDim.x * EL) {
     const int64_t e = e0 + el;
@@ -570,7 +623,6 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float
     sm[threadIdx.x] = a;
     __syncthreads();
     if (g == 0) {
-#pragma unroll
       for (int gg = 1; gg < G; ++gg) a += sm[gg * EL + el];
     }
     __syncthreads();
@@ -691,7 +743,7 @@ extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape,
   if (nblk > 2048) nblk = 2048;
   const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
     hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256),
-                       sizeof(float) * A * shape->hidden[nl - 1], s,
+                       sizeof(float) * 16 * shape->hidden[nl - 1], s,
                        (const float*)w.H[0][nl - 1], (const float*)w.H[1][nl - 1], params + L.off_w[0][nl],
                        params + L.off_b[0][nl], params + L.off_w[1][nl], params + L.off_b[1][nl],
                        params + L.off_logstd, eps, given_action, N, A, action, logprob, value);
@@ -714,7 +766,8 @@ extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, cons
   int64_t nblk = cdiv64(N, 4);
   if (nblk > 2048) nblk = 2048;
   const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
-    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256), 0, s,
+    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256),
+                       sizeof(float) * 16 * shape->hidden[nl - 1], s,
                        (const float*)w.H[0][nl - 1], (const float*)nullptr, params + L.off_w[0][nl],
                        params + L.off_b[0][nl], (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, (float*)nullptr,
@@ -740,7 +793,9 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   CATPPO_CHECK_ARG(ctx, !hp->adv_stats_external || adv_stats != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
-  const int nbg = (int)cdiv64(M, kGatherRows), nbh = (int)cdiv64(M, kHeadRowsPerBlock);
+  const int nbg = (int)cdiv64(M, kGatherRows);
+  int nbh = (int)cdiv64(M, kHeadRowsPerBlock);
+  if (nbh > kHeadMaxBlocks) nbh = kHeadMaxBlocks;
 
   // 1. gather the minibatch (ppo.py:300-302,314,331-337 index with mb_inds)
   hipLaunchKernelGGL(ppo_gather_kernel, dim3(nbg), dim3(256), 0, s, b_obs, b_actions, b_logprobs, b_advantages,
@@ -764,15 +819,15 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
   g.part_w = w.head_w, g.part_s = w.head_s;
   g.M = M, g.A = A, g.hp = *hp;
-  const size_t head_lds = sizeof(float) * ((size_t)A * HL + (size_t)(A + 1) * HL + head_scalars(A));
+  const size_t head_lds =
+      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + head_scalars(A));
   const int rc = dispatch_cpl(HL, [&](auto cpl) {
     constexpr int CPL = decltype(cpl)::value;
-    if (A <= 8)
-      head_loss_kernel<CPL, 8><<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
-    else if (A <= 12)
-      head_loss_kernel<CPL, 12><<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
-    else
-      head_loss_kernel<CPL, 15><<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
+    auto kern = head_loss_kernel<CPL>;
+    if (head_lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)head_lds);
+    kern<<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
   });
   if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
   CATPPO_CHECK_LAUNCH(ctx);
@@ -785,10 +840,22 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     sg.src = src, sg.dst = dst, sg.count = count, sg.stride = stride, sg.n_parts = n_parts, sg.mode = mode,
     sg.scale = scale;
   };
-  // the split-K partial buffers are reused layer after layer, so each layer's partials are folded
-  // by its own reduction launch right after its weight-gradient GEMM
+  // Backward: the data-gradient chain (dX GEMMs) stays on the caller's stream; each layer's weight
+  // gradient (split-K GEMM + fold of its partials) is forked to the side stream as soon as that
+  // layer's dZ exists, and everything is joined before returning to the caller's stream order.
+  // The split-K partial buffers are reused layer after layer; the side stream serialises them.
+  hipStream_t side = ctx->use_side ? ctx->side : s;
+#define CATPPO_HIP_OK(call)                                                                          \
+  do {                                                                                               \
+    hipError_t e__ = (call);                                                                         \
+    if (e__ != hipSuccess)                                                                           \
+      return catppo_fail(ctx, CATPPO_E_HIP, "%s: %s failed: %s", __func__, #call, hipGetErrorString(e__)); \
+  } while (0)
   for (int l = nl - 1; l >= 0; --l) {
     const int out = shape->hidden[l], in = L.in_dim[l];
+    // dZ_l is complete on the main stream here: fork
+    CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
+    CATPPO_HIP_OK(hipStreamWaitEvent(side, ctx->ev_fork[l], 0));
     // weight gradient: dW[out,in] = dZ^T . Xin      (contraction over the M rows)
     Params pw{};
     pw.nets = 2;
@@ -798,7 +865,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     int splits = 512 / (tiles > 0 ? tiles : 1);
     const int max_by_rows = (int)cdiv64(M, 4 * gemm::BK);
     if (splits > max_by_rows) splits = max_by_rows;
-    if (splits > kMaxSplits) splits = kMaxSplits;
+    if (splits > 32) splits = 32;   // partial-sum traffic grows with the split count
     if (splits < 1) splits = 1;
     int per = (int)cdiv64(M, splits);
     per = (per + gemm::BK - 1) / gemm::BK * gemm::BK;
@@ -812,7 +879,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       pw.op[net].C = w.wpart + (int64_t)net * out * in;
       pw.op[net].dbias = w.bpart + (int64_t)net * splits * out;   // [net][split][out]
     }
-    launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, s);
+    launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side);
     CATPPO_CHECK_LAUNCH(ctx);
     segs.n = 0;
     for (int net = 0; net < 2; ++net) {
@@ -830,10 +897,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
       add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, nbh, 1, hp->inv_global_batch);
     }
-    if (l == nl - 1)   // 256 head partials per element: 16 part groups; split-K partials: 4
-      hipLaunchKernelGGL(seg_reduce_kernel<16>, dim3(128, segs.n), dim3(256), 0, s, segs, hp->ent_coef, hp->vf_coef);
-    else
-      hipLaunchKernelGGL(seg_reduce_kernel<4>, dim3(256, segs.n), dim3(256), 0, s, segs, hp->ent_coef, hp->vf_coef);
+    hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);
     CATPPO_CHECK_LAUNCH(ctx);
     if (l > 0) {
       // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
@@ -852,6 +916,9 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       CATPPO_CHECK_LAUNCH(ctx);
     }
   }
+  CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, side));
+  CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+#undef CATPPO_HIP_OK
   return CATPPO_OK;
 }
 
