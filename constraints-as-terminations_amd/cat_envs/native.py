@@ -63,6 +63,9 @@ _SIGNATURES = {
     "catppo_cat_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
     "catppo_cat_terms": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32,
                                    _vp]),
+    "catppo_env_pre_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
+                                      _vp]),
+    "catppo_rollout_store": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
     "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rms_merge": (C.c_int, [_vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
@@ -229,6 +232,20 @@ class Native:
         _chk(episode_length, torch.int64, "episode_length")
         self._ok(self.lib.catppo_cat_reset(self.h, _p(ep_viol), _p(ep_prob), _p(episode_length), _p(mask), n_terms,
                                            N, _p(out), self._stream()))
+
+    # ------------------------------------------------------------------ env bookkeeping
+    def env_pre_step(self, action_in, action, prev_action, episode_length, max_len, hard_reset, reward_src,
+                     time_outs, terminated, reset, reward_out):
+        n, a = action.shape
+        self._ok(self.lib.catppo_env_pre_step(
+            self.h, _p(_chk(action_in, torch.float32, "action")), _p(action), _p(prev_action), a,
+            _p(_chk(episode_length, torch.int64, "episode_length")), int(max_len), _p(hard_reset), hard_reset.stride(0),
+            _p(reward_src), reward_src.stride(0), _p(time_outs), _p(terminated), _p(reset), _p(reward_out), n,
+            self._stream()))
+
+    def rollout_store(self, reward, dones, time_outs, rewards_t, dones_t1, true_dones_t1):
+        self._ok(self.lib.catppo_rollout_store(self.h, _p(reward), _p(dones), _p(time_outs), _p(rewards_t),
+                                               _p(dones_t1), _p(true_dones_t1), reward.numel(), self._stream()))
 
     # ------------------------------------------------------------------ GAE
     def gae(self, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gae_lambda,

@@ -22,6 +22,7 @@ from collections.abc import Sequence
 
 import torch
 
+from cat_envs import native
 from cat_envs.shim import SceneEntityCfg  # noqa: F401  (re-export for term configs)
 
 from .constraint_manager import ConstraintManager
@@ -235,18 +236,18 @@ class CaTEnv:
 
     def step(self, action: torch.Tensor):
         """reference: cat_env.py:42-147 with the physics loop replaced by the synthetic stream."""
-        self.action_manager.process_action(action.to(self.device))
         self._sim_step_counter += self.cfg.decimation
         self.sim.step()
-        # -- counters (cat_env.py:92-93)
-        self.episode_length_buf += 1
         self.common_step_counter += 1
-        # -- terminations (:95-97): hard resets come from the stream, time-outs from the counter
-        torch.ge(self.episode_length_buf, self.max_episode_length, out=self.reset_time_outs)
-        torch.gt(self.sim.view("hard_reset")[:, 0], 0.5, out=self.reset_terminated)
-        torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
+        # -- one launch: process_action, episode_length_buf += 1 (:92), terminations (:95-97: hard resets
+        #    from the stream, time-outs from the counter), reward_manager output -> reward_buf
+        am = self.action_manager
+        action = action if (action.dtype == torch.float32 and action.is_contiguous()) else action.float().contiguous()
+        native.get(self.device).env_pre_step(action, am._action, am._prev_action, self.episode_length_buf,
+                                             self.max_episode_length, self.sim.view("hard_reset"),
+                                             self.sim.view("reward"), self.reset_time_outs, self.reset_terminated,
+                                             self.reset_buf, self.reward_buf)
         # -- CaT (:99-107,118-121): probability, reward *= (1-p) clipped at 0, dones = p, dones[reset] = 1
-        self.reward_buf.copy_(self.sim.view("reward")[:, 0])          # reward_manager.compute(dt)
         if hasattr(self.cfg, "constraints"):
             self.constraint_manager.compute(reward=self.reward_buf, reset_mask=self.reset_buf, dones=self._dones)
             dones = self._dones

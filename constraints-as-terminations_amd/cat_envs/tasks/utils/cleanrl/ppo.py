@@ -309,9 +309,14 @@ class PPOTrainer:
             nat.policy_act(a.shape, a.flat, self.obs[step], N, eps, self.actions[step], self.logprobs[step],
                            self.values[step])
             next_obs, reward, next_done, timeouts, info = self.envs.step(self.actions[step])
-            self.rewards[step].copy_(reward)
-            self.dones[step + 1].copy_(next_done)                # .to(torch.float) happens in the copy
-            self.true_dones[step + 1].copy_(timeouts)
+            if (reward.dtype == torch.float32 and next_done.dtype == torch.float32 and timeouts.dtype == torch.bool
+                    and reward.is_contiguous() and next_done.is_contiguous() and timeouts.is_contiguous()):
+                nat.rollout_store(reward, next_done, timeouts, self.rewards[step], self.dones[step + 1],
+                                  self.true_dones[step + 1])
+            else:                                                # foreign env: dtype conversions in the copies
+                self.rewards[step].copy_(reward)
+                self.dones[step + 1].copy_(next_done)
+                self.true_dones[step + 1].copy_(timeouts)
             if "episode" in info:
                 ep_infos.append(info["episode"])
             elif "log" in info:

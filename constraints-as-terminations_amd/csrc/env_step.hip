@@ -1,0 +1,78 @@
+// Per-env bookkeeping around the CaT step, fused into single launches.
+//   env_pre_step   : counters, terminations and the raw reward of one env step
+//                    (reference cat/cat_env.py:62,92-97: process_action, episode_length_buf += 1,
+//                    termination_manager.compute(): time_outs / terminated / reset_buf; plus the
+//                    reward_manager output copied into reward_buf)   - replaces 7 tiny torch launches
+//   rollout_store  : rewards[step] / dones[step+1] / true_dones[step+1] of the PPO rollout buffer
+//                    (reference cleanrl/ppo.py:215-216,226)            - replaces 3 tiny torch launches
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void env_pre_step_kernel(const float* __restrict__ action_in, float* __restrict__ action,
+                                                           float* __restrict__ prev_action, int A,
+                                                           int64_t* __restrict__ episode_length, int64_t max_len,
+                                                           const float* __restrict__ hard_reset, int64_t hr_stride,
+                                                           const float* __restrict__ reward_src, int64_t rw_stride,
+                                                           uint8_t* __restrict__ time_outs, uint8_t* __restrict__ terminated,
+                                                           uint8_t* __restrict__ reset, float* __restrict__ reward_out,
+                                                           int64_t N) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // action manager: prev <- current, current <- new   (N*A elements)
+  for (int64_t e = tid; e < N * A; e += (int64_t)gridDim.x * 256) {
+    prev_action[e] = action[e];
+    action[e] = action_in[e];
+  }
+  for (int64_t i = tid; i < N; i += (int64_t)gridDim.x * 256) {
+    const int64_t len = episode_length[i] + 1;          // episode_length_buf += 1
+    episode_length[i] = len;
+    const bool to = len >= max_len;                      // time_out termination term
+    const bool term = hard_reset[i * hr_stride] > 0.5f;  // simulator-side hard terminations
+    time_outs[i] = to;
+    terminated[i] = term;
+    reset[i] = to || term;
+    reward_out[i] = reward_src[i * rw_stride];
+  }
+}
+
+__global__ __launch_bounds__(256) void rollout_store_kernel(const float* __restrict__ reward, const float* __restrict__ dones,
+                                                            const uint8_t* __restrict__ time_outs,
+                                                            float* __restrict__ rewards_t, float* __restrict__ dones_t1,
+                                                            float* __restrict__ true_dones_t1, int64_t N) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+    rewards_t[i] = reward[i];
+    dones_t1[i] = dones[i];
+    true_dones_t1[i] = time_outs[i] ? 1.0f : 0.0f;
+  }
+}
+
+}  // namespace
+
+extern "C" int catppo_env_pre_step(catppo_ctx* ctx, const float* action_in, float* action, float* prev_action, int A,
+                                   int64_t* episode_length, int64_t max_episode_length, const float* hard_reset,
+                                   int64_t hard_reset_stride, const float* reward_src, int64_t reward_stride,
+                                   uint8_t* time_outs, uint8_t* terminated, uint8_t* reset, float* reward_out,
+                                   int64_t N, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, action_in && action && prev_action && A >= 1 && episode_length && hard_reset && reward_src);
+  CATPPO_CHECK_ARG(ctx, time_outs && terminated && reset && reward_out && N >= 1);
+  int64_t nblk = cdiv64(N * A, 256);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(env_pre_step_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), action_in,
+                     action, prev_action, A, episode_length, max_episode_length, hard_reset, hard_reset_stride,
+                     reward_src, reward_stride, time_outs, terminated, reset, reward_out, N);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
+                                    float* rewards_t, float* dones_t1, float* true_dones_t1, int64_t N, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, reward && dones && time_outs && rewards_t && dones_t1 && true_dones_t1 && N >= 1);
+  int64_t nblk = cdiv64(N, 256);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(rollout_store_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), reward,
+                     dones, time_outs, rewards_t, dones_t1, true_dones_t1, N);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}

@@ -196,6 +196,22 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[CPL]) {
   }
 }
 
+template <int CPL>
+__device__ __forceinline__ void load_vec(const float* p, float (&v)[CPL]) {
+  if constexpr (CPL == 1) {
+    v[0] = p[0];
+  } else if constexpr (CPL == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x, v[1] = t.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      const float4 t = reinterpret_cast<const float4*>(p)[q];
+      v[4 * q] = t.x, v[4 * q + 1] = t.y, v[4 * q + 2] = t.z, v[4 * q + 3] = t.w;
+    }
+  }
+}
+
 // Sixteen per-lane partial values -> their 64-lane totals with 17 cross-lane exchanges instead of
 // 16 x 6: every butterfly step halves the number of live values (the lane keeps the half selected by
 // its own bit and hands the other half to its partner).  Afterwards the total of value j sits in the
@@ -262,9 +278,10 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
       for (int c = 0; c < CPL; ++c) ha[c] = Ha[i * HL + lane * CPL + c];
 #pragma unroll
       for (int k = 0; k < VS; ++k) {
-        float d = 0.0f;
+        float d = 0.0f, wk[CPL];
+        load_vec<CPL>(lds + k * HL + lane * CPL, wk);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], lds[k * HL + lane * CPL + c], d);
+        for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], wk[c], d);
         part[k] = d;
       }
     } else {
@@ -353,7 +370,7 @@ struct HeadArgs {
 static_assert(kHeadRowsPerBlock == 32, "8 waves x 4 rows per tile");
 constexpr int kHeadWaves = 8;        // waves per block
 constexpr int kHeadRowsPerWave = 4;  // rows of a tile handled by one wave
-constexpr int kHeadMaxBlocks = 256;  // = number of weight-gradient partials folded afterwards
+constexpr int kHeadMaxBlocks = 512;  // = number of weight-gradient partials folded afterwards (2 blocks per CU)
 
 // Heads + PPO loss + backward through the heads, one tile of 32 minibatch rows at a time:
 //   phase 1 (wave per row)  last-hidden rows -> registers AND an LDS tile; A+1 dot products per row
@@ -452,23 +469,18 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss
       if (r >= rows) break;                        // wave-uniform
       const int64_t i = row0 + r;
       float hc[CPL], ha[CPL], part[16];
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        hc[c] = g.Hc[i * HL + lane * CPL + c];
-        ha[c] = g.Ha[i * HL + lane * CPL + c];
-      }
+      load_vec<CPL>(g.Hc + i * HL + lane * CPL, hc);
+      load_vec<CPL>(g.Ha + i * HL + lane * CPL, ha);
       const float a_taken = mine ? g.act[i * A + slot] : 0.0f;
       const float oldlogp = g.oldlogp[i], adv_raw = g.adv[i], R = g.ret_n[i], Vo = g.val_n[i];
-#pragma unroll
-      for (int c = 0; c < CPL; ++c) {
-        sHc[r * HL + lane * CPL + c] = hc[c];
-        sHa[r * HL + lane * CPL + c] = ha[c];
-      }
+      store_vec<CPL>(sHc + r * HL + lane * CPL, hc);
+      store_vec<CPL>(sHa + r * HL + lane * CPL, ha);
 #pragma unroll
       for (int k = 0; k < VS; ++k) {
-        float d = 0.0f;
+        float d = 0.0f, wk[CPL];
+        load_vec<CPL>(s_wa + k * HL + lane * CPL, wk);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], s_wa[k * HL + lane * CPL + c], d);
+        for (int c = 0; c < CPL; ++c) d = fmaf(ha[c], wk[c], d);
         part[k] = d;
       }
       {
@@ -532,8 +544,10 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss
 #pragma unroll
       for (int k = 0; k < VS; ++k) {
         const float gmk = lane_bcast(gm, slot_lane(k));
+        float wk[CPL];
+        load_vec<CPL>(s_wa + k * HL + lane * CPL, wk);
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) dha[c] = fmaf(gmk, s_wa[k * HL + lane * CPL + c], dha[c]);
+        for (int c = 0; c < CPL; ++c) dha[c] = fmaf(gmk, wk[c], dha[c]);
       }
       float oa[CPL], oc[CPL];
 #pragma unroll
@@ -548,9 +562,10 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss
     // ------------------------------------------------------------------ phase 2: dW4 += G^T . H
     for (int r = 0; r < rows; ++r) {
       const float ha2 = sHa[r * HL + c2], hc2 = sHc[r * HL + c2];
+      float gk[KPG];
+      load_vec<KPG>(sG + r * 16 + k0, gk);        // k0 is a multiple of KPG: one or two b128 broadcasts
 #pragma unroll
-      for (int kk = 0; kk < KPG; ++kk)
-        acc[kk] = fmaf(sG[r * 16 + k0 + kk], (k0 + kk) == VS ? hc2 : ha2, acc[kk]);
+      for (int kk = 0; kk < KPG; ++kk) acc[kk] = fmaf(gk[kk], (k0 + kk) == VS ? hc2 : ha2, acc[kk]);
     }
     if (tid < 16) {
       for (int r = 0; r < rows; ++r) accb += sG[r * 16 + tid];

@@ -107,6 +107,59 @@ __global__ __launch_bounds__(kThreads) void rms_merge(const double* __restrict__
   if (threadIdx.x == 0) count[0] = tot;
 }
 
+// single-GPU update: fold the partials and merge in ONE launch (2*D <= kFusedMax sums staged in LDS)
+constexpr int kFusedMax = 1024;
+__global__ __launch_bounds__(kThreads) void rms_final_merge(const double* __restrict__ partial, int nblk, double n,
+                                                            int D, float* __restrict__ mean, float* __restrict__ var,
+                                                            float* __restrict__ count) {
+  __shared__ double sums[kFusedMax];
+  __shared__ double sm[kThreads];
+  const int W = 2 * D;
+  const int Wc = W < kThreads ? W : kThreads;
+  const int G = kThreads / Wc;
+  const int c0 = threadIdx.x % Wc, g = threadIdx.x / Wc;
+  for (int cb = 0; cb < W; cb += Wc) {
+    const int c = cb + c0;
+    double a = 0.0;
+    if (g < G && c < W) {
+#pragma unroll 8
+      for (int b = g; b < nblk; b += G) a += partial[(int64_t)b * W + c];
+    }
+    sm[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0 && c < W) {
+      for (int gg = 1; gg < G; ++gg) a += sm[gg * Wc + c0];
+      sums[c] = a;
+    }
+    __syncthreads();
+  }
+  const float cnt = count[0];
+  const float nf = (float)n;
+  const float tot = cnt + nf;
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    const double m = sums[c] / n;
+    double v = sums[D + c] / n - m * m;
+    if (v < 0.0) v = 0.0;
+    const float bm = (float)m, bv = (float)v;
+    const float delta = bm - mean[c];
+    float t = delta * nf;
+    t = t / tot;
+    const float new_mean = mean[c] + t;
+    const float m_a = var[c] * cnt;
+    const float m_b = bv * nf;
+    float d2 = delta * delta;
+    d2 = d2 * cnt;
+    d2 = d2 * nf;
+    d2 = d2 / tot;
+    float M2 = m_a + m_b;
+    M2 = M2 + d2;
+    mean[c] = new_mean;
+    var[c] = M2 / tot;
+  }
+  if (threadIdx.x == 0) count[0] = tot;
+}
+
 __global__ __launch_bounds__(kThreads) void rms_normalize(const float* __restrict__ x, int64_t N, int D,
                                                           int64_t ldx, const float* __restrict__ mean,
                                                           const float* __restrict__ var, float eps,
@@ -177,6 +230,15 @@ extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int
   double* sums = ws.take<double>((uint64_t)2 * D);
   CATPPO_NEED_WS(ctx, partial);
   CATPPO_NEED_WS(ctx, sums);
+  if (2 * D <= kFusedMax) {
+    const int rows_per_block = (kThreads / Dc) * 16;
+    hipLaunchKernelGGL(rms_moments_partial, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
+    CATPPO_CHECK_LAUNCH(ctx);
+    hipLaunchKernelGGL(rms_final_merge, dim3(1), dim3(kThreads), 0, s, (const double*)partial, nblk, (double)N, D, mean,
+                       var, count);
+    CATPPO_CHECK_LAUNCH(ctx);
+    return CATPPO_OK;
+  }
   if (int rc = launch_moments(ctx, x, N, D, ldx, sums, s)) return rc;
   hipLaunchKernelGGL(rms_merge, dim3(1), dim3(kThreads), 0, s, sums, (double)N, D, mean, var, count);
   CATPPO_CHECK_LAUNCH(ctx);

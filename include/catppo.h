@@ -137,6 +137,21 @@ int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms,
                      const float* forces, int64_t forces_env_stride, int H, int B,
                      const float* command, int command_ld, float* cstr, int K, void* stream);
 
+/* ---- env-step bookkeeping, fused ------------------------------------------------------------
+ * catppo_env_pre_step: process_action (prev <- action, action <- action_in, [N,A]); episode_length += 1;
+ *   time_outs = episode_length >= max_episode_length; terminated = hard_reset > 0.5; reset = either;
+ *   reward_out = reward_src (the reward manager's output, strided view allowed).  time_outs /
+ *   terminated / reset are uint8 (torch.bool) [N].   replaces: cat/cat_env.py:62,92-97.
+ * catppo_rollout_store: rewards[step] = reward, dones[step+1] = dones, true_dones[step+1] =
+ *   float(time_outs).   replaces: cleanrl/ppo.py:215-216,226. */
+int catppo_env_pre_step(catppo_ctx* ctx, const float* action_in, float* action, float* prev_action, int A,
+                        int64_t* episode_length, int64_t max_episode_length, const float* hard_reset,
+                        int64_t hard_reset_stride, const float* reward_src, int64_t reward_stride,
+                        uint8_t* time_outs, uint8_t* terminated, uint8_t* reset, float* reward_out,
+                        int64_t N, void* stream);
+int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
+                         float* rewards_t, float* dones_t1, float* true_dones_t1, int64_t N, void* stream);
+
 /* ---- GAE -------------------------------------------------------------------------------
  * time-major (T,N) buffers; float dones in [0,1]; separate time-out mask.
  *   nn = 1-d_{t+1}, tn = 1-td_{t+1}
