@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
                                                        float* __restrict__ value) {
   constexpr int HL = CPL * 64;
   constexpr int VS = 15;
-  extern __shared__ float lds[];   // [16*HL] actor head weights, rows >= A zero
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [16*HL] actor head weights, rows >= A zero
   const int lane = threadIdx.x & 63;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -387,8 +387,9 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss
   constexpr int KPG = 16 / NG;                         // head outputs per group (16 slots)
   constexpr int TR = kHeadRowsPerBlock;
   constexpr int VS = 15;                               // slot of the critic output; actions use slots 0..A-1
+  // ALL shared memory lives in the dynamic region: a static __shared__ object in front of it would
+  // shift its base off 16-B alignment and every ds_read_b128 below would be replayed (64 cycles each)
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  __shared__ float s_adv[2];
   const int A = g.A;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NS = 2 * A + 1 + kHeadDiag;
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss
   float* sHc = sHa + TR * HL;              // [TR*HL]  critic last-hidden tile
   float* sG = sHc + TR * HL;               // [TR*16]  per-row head gradients: d mu_k (k<A), 0, ..., d v at VS
   float* ls = sG + TR * 16;                // [NS]     scalars: db4a[A], db4c, dlogstd[A], diag[8]
+  float* s_adv = ls + 48;                  // [2]      advantage mean, std + 1e-8   (NS <= 2*15+1+8 = 39)
 
   for (int o = tid; o < 16 * HL; o += NT) s_wa[o] = o < A * HL ? g.W4a[o] : 0.0f;
   for (int o = tid; o < TR * 16; o += NT) sG[o] = 0.0f;
@@ -835,7 +837,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   g.part_w = w.head_w, g.part_s = w.head_s;
   g.M = M, g.A = A, g.hp = *hp;
   const size_t head_lds =
-      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + head_scalars(A));
+      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
   const int rc = dispatch_cpl(HL, [&](auto cpl) {
     constexpr int CPL = decltype(cpl)::value;
     auto kern = head_loss_kernel<CPL>;
