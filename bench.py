@@ -83,9 +83,10 @@ def pick_cpu_threads(obs_dim, hidden):
     return best
 
 
-def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=25.0):
+def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=15.0):
     """the oracle (torch-CPU restatement of PPO() + numpy CaT) timed on the host cores, rank 0 / N=1 only,
-    on a bounded sample of the same workload"""
+    on a bounded sample of the same workload: whole iterations (24 steps + GAE + 5 epochs x 6 minibatches)
+    after one untimed warm-up iteration, until ~budget_s seconds of CPU work have been measured"""
     from oracle import env_oracle, ppo_oracle
     w = WORKLOADS[workload]
     cores = pick_cpu_threads(trainer.D, w["hidden"])
@@ -93,21 +94,33 @@ def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=25.0):
     cpu_env = env_oracle.from_device_env(env)
     ag = ppo_oracle.AgentOracle(trainer.D, trainer.A, w["hidden"], seed=0)
     cfg = {k: getattr(agent_cfg, k) for k in ppo_oracle.PPOOracle.DEFAULT_CFG}
-    # bounded sample: ONE epoch of the update instead of five (the update is ~95% of the time and
-    # linear in the epoch count), then scaled back to the full iteration
-    cfg["updates_epochs"] = 1
     orc = ppo_oracle.PPOOracle(cpu_env, w["num_envs"], trainer.D, trainer.A, cfg=cfg, hidden=w["hidden"], agent=ag)
-    t0 = time.perf_counter()
-    orc.run_iteration()
+    orc.run_iteration()                                   # warm-up (allocator, thread pool)
+    for k in orc.timers:
+        orc.timers[k] = 0.0
+    n, t0 = 0, time.perf_counter()
+    while n < 8 and (time.perf_counter() - t0) < budget_s:
+        orc.run_iteration()
+        n += 1
     dt = time.perf_counter() - t0
     tm = orc.timers
-    full = tm["rollout"] + tm["gae"] + 5.0 * tm["update"]
-    steps = w["num_envs"] * w["num_steps"]
-    return {"value": steps / full, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 iteration of {w['num_envs']}x{w['num_steps']} with 1 of 5 update epochs timed "
-                      f"({dt:.1f} s wall), update time scaled x5",
-            "phase_ms": {"rollout_fwd_and_env": 1e3 * tm["rollout"], "cat_env_step": 1e3 * tm["env"],
-                         "gae": 1e3 * tm["gae"], "update_5_epochs": 5e3 * tm["update"]}}
+    steps = w["num_envs"] * w["num_steps"] * n
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full iterations of {w['num_envs']}x{w['num_steps']} (5 epochs x 6 minibatches of 16384) "
+                      f"after 1 warm-up iteration, {dt:.1f} s wall",
+            "phase_ms_per_iteration": {"rollout_fwd_and_env": 1e3 * tm["rollout"] / n, "cat_env_step": 1e3 * tm["env"] / n,
+                                       "gae": 1e3 * tm["gae"] / n, "update": 1e3 * tm["update"] / n}}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel group from the committed PMC summary (separate
+    rocprofv3 --pmc passes cannot run inside the timed process); None when no summary matches"""
+    path = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def gae_roofline(nat, T, N, reps=50):
@@ -208,7 +221,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad (gather, 2x3 grouped fp32-MFMA GEMM launches fwd, "
                          "head+loss, split-K dW + dX GEMMs, partial reductions) per 16384-sample minibatch",
                          "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": None, "avg_launch_us": grad_us, "flops_per_launch": flops_per_launch},
+                         "traffic": pmc_traffic(a.workload), "avg_launch_us": grad_us,
+                         "flops_per_launch": flops_per_launch,
+                         "traffic_source": "profiles/r1_pmc_traffic_cfg2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                                           "of this command, FETCH x2 gfx950 correction)"},
             "gae": {"config_size": gae_roofline(nat, w["num_steps"], w["num_envs"]),
                     "hbm_sweep": [gae_roofline(nat, 24, 1 << 20, 20), gae_roofline(nat, 48, 1 << 22, 10)],
                     "bound": "hbm", "peak_GBps": HBM_PEAK_GBPS, "bytes_per_env_step": 24},

@@ -83,8 +83,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   const int net = blockIdx.z % p.nets;
   const int split = blockIdx.z / p.nets;
   const Operands op = p.op[net];   // by value: pointers live in SGPRs for the whole kernel
-  const int i0 = blockIdx.y * BM;
-  const int j0 = blockIdx.x * BN;
+  // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, each XCD has a private L2.  Give
+  // every XCD a contiguous range of the tile sequence (j fastest), so the tiles that share an A row
+  // block hit the same L2 instead of fetching it once per XCD through the fabric.
+  const int tiles_j = (p.J + BN - 1) / BN;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int i0 = (wg / tiles_j) * BM;
+  const int j0 = (wg % tiles_j) * BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   float dbsum = 0.0f;  // EPI_PARTIAL: column sum of A for output row i0+tid (tid < BM)
-  const bool do_db = (EPI == EPI_PARTIAL) && op.dbias != nullptr && blockIdx.x == 0;
+  const bool do_db = (EPI == EPI_PARTIAL) && op.dbias != nullptr && j0 == 0;
 
   const int n_slabs = (k_end - k_begin + BK - 1) / BK;
   if (n_slabs > 0) {

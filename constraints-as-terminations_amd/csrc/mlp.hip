@@ -125,7 +125,7 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
 // ------------------------------------------------------------------------------- GEMM launch
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 void launch_gemm(const Params& p, hipStream_t s) {
-  dim3 grid((p.J + BN - 1) / BN, (p.I + BM - 1) / BM, p.nets * p.splits);
+  dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);   // 1-D tile index, see kernel
   constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
   gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI><<<grid, dim3(256), lds, s>>>(p);
 }

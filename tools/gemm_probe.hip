@@ -20,7 +20,7 @@ using gemm::Params;
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = 16>
 float run(const Params& p, int reps) {
-  dim3 grid((p.J + BN - 1) / BN, (p.I + BM - 1) / BM, p.nets * p.splits);
+  dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);
   constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC, BKT>();
   if (lds > 64 * 1024)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, BKT>),
