@@ -156,8 +156,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("CATPPO_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
@@ -231,10 +234,20 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, trainer, env, agent_cfg)
-        print(json.dumps(out))
-    if world > 1:
+    else:
+        out = None
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if out is not None:
+        # RCCL writes a version banner through C stdio: flush it first so that the JSON is the last line
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

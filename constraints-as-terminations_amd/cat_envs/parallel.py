@@ -12,8 +12,12 @@ helpers are device agnostic (gloo on CPU in the tests, RCCL on the GPUs).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
+
+_FORCE = os.environ.get("CATPPO_FORCE_DIST", "0") == "1"
 
 
 def world_size(group=None) -> int:
@@ -25,7 +29,11 @@ def rank(group=None) -> int:
 
 
 def active(group=None) -> bool:
-    return world_size(group) > 1
+    """True when the exchange points must run.  CATPPO_FORCE_DIST=1 turns them on for an initialised
+    world of size 1 too, so the two-phase kernels + collectives can be exercised on a single GPU."""
+    if world_size(group) > 1:
+        return True
+    return _FORCE and dist.is_available() and dist.is_initialized()
 
 
 def shard_slice(n_total: int, r: int, w: int) -> slice:

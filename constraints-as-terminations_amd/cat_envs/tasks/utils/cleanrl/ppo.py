@@ -258,7 +258,7 @@ class PPOTrainer:
         self.agent = agent if agent is not None else Agent(envs, hidden=hidden).to(self.device)
         a = self.agent
         self.D, self.A, self.Dp = a.obs_dim, a.act_dim, a.layout.obs_pad
-        if self.world > 1:
+        if parallel.active():
             parallel.broadcast_(a.flat, src=0)                  # replicas start identical (cf. skrl ppo.py:126-131)
             a.obs_rms.dist_group = a.value_rms.dist_group = torch.distributed.group.WORLD
             cm = getattr(envs.unwrapped, "constraint_manager", None)
@@ -349,7 +349,7 @@ class PPOTrainer:
         b_ret, b_val = self.returns_n.view(-1), self.values_n.view(-1)
         vmean, vvar = a.value_rms.running_mean, a.value_rms.running_var
         self.diag.zero_()
-        exact_adv = self.world > 1 and bool(c.norm_adv) and getattr(c, "dist_exact", True)
+        exact_adv = parallel.active() and bool(c.norm_adv) and getattr(c, "dist_exact", True)
         for epoch in range(int(c.updates_epochs)):
             inds = torch.randperm(B, device=self.device) if perm_fn is None else perm_fn(epoch)
             for start in range(0, B, M):

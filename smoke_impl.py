@@ -37,12 +37,13 @@ def make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden=(512, 256, 1
 
 
 def run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=1, hidden=(512, 256, 128), six_terms=True,
-             seed=42):
+             seed=42, obs_dim=45):
     """returns (trainer, oracle, per-iteration oracle outputs)"""
     from cat_envs.shim import make
     from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
     from oracle import env_oracle, ppo_oracle
-    task, env_cfg, agent_cfg = make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden, six_terms, seed=seed)
+    task, env_cfg, agent_cfg = make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden, six_terms, seed=seed,
+                                         obs_dim=obs_dim)
     env = make(task, cfg=env_cfg)
     trainer = PPOTrainer(env, agent_cfg)
     sd = {k: v.detach().cpu().clone() for k, v in trainer.agent.state_dict().items()}

@@ -85,3 +85,45 @@ def test_reference_api_surface_on_device():
         _, lp4, _, _ = o.get_action_and_value(x.cpu(), a2 * 1.1)
     np.testing.assert_allclose(lp3.cpu().numpy(), lp4.numpy(), rtol=1e-5, atol=1e-4)
     assert ag(x).shape == (33, 12)
+
+
+def test_config4_long_horizon_wide_obs():
+    """BASELINE config 4 shapes: horizon 48, 235-d observations (48 + 187 height scan), 3x256 MLP"""
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=128, num_steps=48, minibatch=2048, epochs=1, iters=1,
+                                             hidden=(256, 256, 256), obs_dim=235)
+    assert trainer.Dp == 240 and trainer.obs.shape == (49, 128, 240)
+    smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+
+
+def test_config3_per_gpu_shard_full_constraints():
+    """BASELINE config 3, one rank's share: 2048 envs, full 13-term ConstraintsCfg, reference MLP"""
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=2048, num_steps=4, minibatch=2048, epochs=1, iters=1,
+                                             six_terms=False)
+    smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+
+
+def test_env_sharded_code_path_on_one_gpu():
+    """CATPPO_FORCE_DIST=1: RCCL world of size 1, every exchange point active (two-phase CaT step with the
+    MAX all-reduce, fp64 moment sums, external advantage statistics, flat-gradient all-reduce)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, sys\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29577', RANK='0', WORLD_SIZE='1')\n"
+        "torch.cuda.set_device(0)\n"
+        "torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "import smoke_impl\n"
+        "from cat_envs import parallel\n"
+        "assert parallel.active()\n"
+        "t, o, outs = smoke_impl.run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=2)\n"
+        "assert t.envs.constraint_manager.dist_group is not None and t.agent.obs_rms.dist_group is not None\n"
+        "print(smoke_impl.compare(t, o, outs[-1], tol_scale=2.0))\n"
+        "torch.distributed.destroy_process_group()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CATPPO_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=os.pathsep.join([root, os.path.join(root, "constraints-as-terminations_amd")]))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
