@@ -66,6 +66,8 @@ _SIGNATURES = {
     "catppo_env_pre_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                       _vp]),
     "catppo_rollout_store": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "catppo_adv_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "catppo_adv_stats": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
     "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rms_merge": (C.c_int, [_vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
@@ -246,6 +248,15 @@ class Native:
     def rollout_store(self, reward, dones, time_outs, rewards_t, dones_t1, true_dones_t1):
         self._ok(self.lib.catppo_rollout_store(self.h, _p(reward), _p(dones), _p(time_outs), _p(rewards_t),
                                                _p(dones_t1), _p(true_dones_t1), reward.numel(), self._stream()))
+
+    def adv_moments(self, advantages, inds, minibatch, moments):
+        _chk(inds, torch.int64, "inds")
+        _chk(moments, torch.float64, "moments")
+        self._ok(self.lib.catppo_adv_moments(self.h, _p(advantages), _p(inds), inds.numel(), int(minibatch),
+                                             _p(moments), self._stream()))
+
+    def adv_stats(self, moments, n_minibatches, stats):
+        self._ok(self.lib.catppo_adv_stats(self.h, _p(moments), int(n_minibatches), _p(stats), self._stream()))
 
     # ------------------------------------------------------------------ GAE
     def gae(self, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gae_lambda,

@@ -349,16 +349,27 @@ class PPOTrainer:
         b_ret, b_val = self.returns_n.view(-1), self.values_n.view(-1)
         vmean, vvar = a.value_rms.running_mean, a.value_rms.running_var
         self.diag.zero_()
+        E = int(c.updates_epochs)
+        n_mb = (B + M - 1) // M
         exact_adv = parallel.active() and bool(c.norm_adv) and getattr(c, "dist_exact", True)
-        for epoch in range(int(c.updates_epochs)):
-            inds = torch.randperm(B, device=self.device) if perm_fn is None else perm_fn(epoch)
-            for start in range(0, B, M):
+        perms = [torch.randperm(B, device=self.device) if perm_fn is None else perm_fn(e) for e in range(E)]
+        if exact_adv:
+            # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318): the moments of every
+            # minibatch of the iteration in one launch per epoch, ONE all-reduce, one finishing launch
+            if not hasattr(self, "_adv_mom") or self._adv_mom.shape[0] != E * n_mb:
+                self._adv_mom = torch.zeros(E * n_mb, 3, dtype=torch.float64, device=self.device)
+                self._adv_stats_all = torch.zeros(E * n_mb, 2, device=self.device)
+            for e in range(E):
+                nat.adv_moments(b_adv, perms[e], M, self._adv_mom[e * n_mb:(e + 1) * n_mb])
+            parallel.allreduce_sum_(self._adv_mom)
+            nat.adv_stats(self._adv_mom, E * n_mb, self._adv_stats_all)
+        self.hp.adv_stats_external = int(exact_adv)
+        for epoch in range(E):
+            inds = perms[epoch]
+            for k, start in enumerate(range(0, B, M)):
                 mb = inds[start:start + M]
                 self.hp.inv_global_batch = 1.0 / (mb.numel() * self.world)
-                adv_stats = None
-                if exact_adv:      # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318)
-                    adv_stats = parallel.global_adv_stats(b_adv[mb], out=self.adv_stats)
-                self.hp.adv_stats_external = int(adv_stats is not None)
+                adv_stats = self._adv_stats_all[epoch * n_mb + k] if exact_adv else None
                 nat.ppo_minibatch_grad(a.shape, self.hp, a.flat, b_obs, b_act, b_logp, b_adv, b_ret, b_val, mb,
                                        vmean, vvar, adv_stats, self.grad, self.diag)
                 parallel.allreduce_sum_(self.grad)              # RCCL SUM of the flat gradient over xGMI

@@ -76,3 +76,68 @@ extern "C" int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const 
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Advantage moments of EVERY minibatch of an iteration in one launch (env-sharded exact mode):
+// out[m] = { sum_i adv[inds[m*mb + i]], sum_i adv[...]^2 } in fp64, fixed order.  The ranks then
+// exchange all minibatches' moments with ONE all-reduce per iteration instead of one per minibatch.
+namespace {
+__global__ __launch_bounds__(256) void adv_moments_kernel(const float* __restrict__ adv, const int64_t* __restrict__ inds,
+                                                          int64_t total, int64_t mb, double* __restrict__ out) {
+  __shared__ double s1[256], s2[256];
+  const int64_t lo = (int64_t)blockIdx.x * mb;
+  const int64_t hi = lo + mb < total ? lo + mb : total;
+  double a = 0.0, b = 0.0;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const double v = (double)adv[inds[i]];
+    a += v;
+    b += v * v;
+  }
+  s1[threadIdx.x] = a, s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (threadIdx.x < w) {
+      s1[threadIdx.x] += s1[threadIdx.x + w];
+      s2[threadIdx.x] += s2[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[3 * blockIdx.x] = s1[0];
+    out[3 * blockIdx.x + 1] = s2[0];
+    out[3 * blockIdx.x + 2] = (double)(hi - lo);
+  }
+}
+
+// moments (after the SUM all-reduce) -> {mean, unbiased std + 1e-8} per minibatch (ppo.py:316-318)
+__global__ void adv_stats_kernel(const double* __restrict__ mom, int n, float* __restrict__ stats) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n) return;
+  const double cnt = mom[3 * m + 2];
+  const double mean = mom[3 * m] / cnt;
+  double var = (mom[3 * m + 1] - cnt * mean * mean) / (cnt - 1.0);
+  if (var < 0.0) var = 0.0;
+  stats[2 * m] = (float)mean;
+  stats[2 * m + 1] = (float)sqrt(var) + 1e-8f;
+}
+}  // namespace
+
+extern "C" int catppo_adv_moments(catppo_ctx* ctx, const float* advantages, const int64_t* inds, int64_t total,
+                                  int64_t minibatch, double* moments, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, advantages && inds && moments && total >= 1 && minibatch >= 1);
+  const int64_t n_mb = cdiv64(total, minibatch);
+  hipLaunchKernelGGL(adv_moments_kernel, dim3((unsigned)n_mb), dim3(256), 0, static_cast<hipStream_t>(stream), advantages,
+                     inds, total, minibatch, moments);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_adv_stats(catppo_ctx* ctx, const double* moments, int n_minibatches, float* stats, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, moments && stats && n_minibatches >= 1);
+  hipLaunchKernelGGL(adv_stats_kernel, dim3((n_minibatches + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     moments, n_minibatches, stats);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}

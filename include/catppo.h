@@ -152,6 +152,14 @@ int catppo_env_pre_step(catppo_ctx* ctx, const float* action_in, float* action, 
 int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
                          float* rewards_t, float* dones_t1, float* true_dones_t1, int64_t N, void* stream);
 
+/* env-sharded exact mode: advantage moments of every minibatch of a (multi-)epoch permutation in one
+ * launch, moments[m] = {sum, sum of squares, count} (fp64) over adv[inds[m*mb : (m+1)*mb]]; after ONE
+ * SUM all-reduce catppo_adv_stats turns them into {mean, unbiased std + 1e-8} per minibatch, the
+ * `adv_stats` input of catppo_ppo_minibatch_grad.   replaces: cleanrl/ppo.py:314-318 across ranks. */
+int catppo_adv_moments(catppo_ctx* ctx, const float* advantages, const int64_t* inds, int64_t total,
+                       int64_t minibatch, double* moments, void* stream);
+int catppo_adv_stats(catppo_ctx* ctx, const double* moments, int n_minibatches, float* stats, void* stream);
+
 /* ---- GAE -------------------------------------------------------------------------------
  * time-major (T,N) buffers; float dones in [0,1]; separate time-out mask.
  *   nn = 1-d_{t+1}, tn = 1-td_{t+1}
