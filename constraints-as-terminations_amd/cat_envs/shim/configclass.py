@@ -49,7 +49,13 @@ def _to_dict(obj):
         return type(obj)(_to_dict(v) for v in obj)
     if callable(obj) and hasattr(obj, "__module__") and hasattr(obj, "__name__"):
         return f"{obj.__module__}:{obj.__name__}"
-    return obj
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if isinstance(obj, slice):
+        return f"slice({obj.start},{obj.stop},{obj.step})"
+    if hasattr(obj, "__dict__"):      # plain config objects such as SceneEntityCfg
+        return {k: _to_dict(v) for k, v in vars(obj).items() if not k.startswith("_")}
+    return str(obj)
 
 
 def configclass(cls=None, **kwargs):

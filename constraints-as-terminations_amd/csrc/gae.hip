@@ -14,32 +14,26 @@
 
 namespace {
 
-template <int VEC>
-struct Vec;
-template <>
-struct Vec<1> {
-  using type = float;
-};
-template <>
-struct Vec<4> {
-  using type = float4;
-};
-
+// every element of the (T,N) planes is touched exactly once: stream them past the caches (nt)
 template <int VEC>
 __device__ __forceinline__ void load(const float* p, float (&v)[VEC]) {
   if constexpr (VEC == 1) {
-    v[0] = *p;
+    v[0] = __builtin_nontemporal_load(p);
   } else {
-    const float4 q = *reinterpret_cast<const float4*>(p);
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
     v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
   }
 }
 template <int VEC>
 __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
   if constexpr (VEC == 1) {
-    *p = v[0];
+    __builtin_nontemporal_store(v[0], p);
   } else {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    using f4 = __attribute__((ext_vector_type(4))) float;
+    f4 q;
+    q.x = v[0], q.y = v[1], q.z = v[2], q.w = v[3];
+    __builtin_nontemporal_store(q, reinterpret_cast<f4*>(p));
   }
 }
 

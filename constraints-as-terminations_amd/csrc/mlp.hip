@@ -11,6 +11,7 @@
 #include "gemm_f32.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -602,6 +603,8 @@ __global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss
   for (int o = tid; o < NS; o += NT) ps[o] = ls[o];
 }
 
+#include "fused_rows.h"
+
 // ------------------------------------------------------------------------------- segmented partial reduction
 // dst[e] (+)= scale * sum_{p<n_parts} src[p*stride + e]   in fixed order.  One launch handles every segment
 // (all split-K weight/bias partials, the head partials and the diagnostics).
@@ -708,6 +711,56 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
   }
 }
 
+void fill_fused(FusedArgs& f, const catppo_mlp_shape* sh, const catppo_mlp_layout& L, const float* params,
+                const float* x, int64_t M, const MlpWs& w, bool training) {
+  f = FusedArgs{};
+  f.x = x, f.params = params, f.n_hidden = sh->n_hidden, f.A = sh->act_dim, f.Dp = L.obs_pad, f.M = M;
+  f.off_logstd = L.off_logstd;
+  for (int l = 0; l < sh->n_hidden; ++l) f.hidden[l] = sh->hidden[l];
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l <= sh->n_hidden; ++l) f.off_w[net][l] = L.off_w[net][l], f.off_b[net][l] = L.off_b[net][l];
+  if (training)
+    for (int net = 0; net < 2; ++net)
+      for (int l = 0; l < sh->n_hidden; ++l) f.H[net][l] = w.H[net][l], f.dZ[net][l] = w.dZ[net][l];
+}
+
+// 0: layer-wise path; otherwise 1 + variant of the fused row-tile kernel (see launch_fused)
+int fused_variant(const catppo_mlp_shape* sh) {
+  static const int forced = [] {
+    // measured on MI355X (profiles/): the fused kernel is correct but 10-20 % SLOWER than the
+    // layer-wise path (one workgroup per CU runs its phases in lock-step, so head / epilogue phases
+    // never overlap MFMA work), hence opt-in: "1".."3" selects a variant, unset / "0" = layer-wise
+    const char* e = getenv("CATPPO_FUSED");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced <= 0) return 0;
+  int maxw = 0;
+  for (int l = 0; l < sh->n_hidden; ++l) maxw = sh->hidden[l] > maxw ? sh->hidden[l] : maxw;
+  if (maxw > 512) return 0;
+  if (maxw > 256) return 3;
+  return forced >= 3 ? 3 : forced;
+}
+inline int fused_rows(int variant_plus1) { return variant_plus1 == 1 ? 64 : 32; }
+
+template <int R, int MAXW, int NW, bool TRAIN>
+void launch_fused_cfg(const FusedArgs& f, int nets, hipStream_t s) {
+  constexpr size_t lds = fused_lds_bytes<R, MAXW>();
+  auto kern = fused_rows_kernel<R, MAXW, NW, TRAIN>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  kern<<<dim3((unsigned)cdiv64(f.M, R), nets), dim3(NW * 64), lds, s>>>(f);
+}
+
+// variant: 0 = 64-row tiles / 8 waves (one workgroup per CU), 1 = 32-row tiles / 4 waves (two independent
+// workgroups per CU: their barrier bubbles overlap), 2 = 32-row tiles / 8 waves for widths up to 512
+template <bool TRAIN>
+int launch_fused(catppo_ctx* ctx, const FusedArgs& f, int variant, int nets, hipStream_t s) {
+  if (variant == 0) launch_fused_cfg<64, 256, 8, TRAIN>(f, nets, s);
+  else if (variant == 1) launch_fused_cfg<32, 256, 4, TRAIN>(f, nets, s);
+  else launch_fused_cfg<32, 512, 8, TRAIN>(f, nets, s);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
 template <typename F>
 int dispatch_cpl(int hl, F&& f) {
   switch (hl) {
@@ -753,6 +806,12 @@ extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape,
   if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
   CATPPO_CHECK_ARG(ctx, params && x && action && logprob && value);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int fv = fused_variant(shape)) {
+    FusedArgs f;
+    fill_fused(f, shape, L, params, x, N, w, false);
+    f.eps = eps, f.given = given_action, f.action = action, f.logprob = logprob, f.value = value;
+    return launch_fused<false>(ctx, f, fv - 1, 2, s);
+  }
   forward_hidden(shape, L, params, x, N, w, 0, 2, s);
   CATPPO_CHECK_LAUNCH(ctx);
   const int nl = shape->n_hidden, A = shape->act_dim;
@@ -777,6 +836,12 @@ extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, cons
   if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
   CATPPO_CHECK_ARG(ctx, params && x && value);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (const int fv = fused_variant(shape)) {
+    FusedArgs f;
+    fill_fused(f, shape, L, params, x, N, w, false);
+    f.value = value;
+    return launch_fused<false>(ctx, f, fv - 1, 1, s);   // grid.y == 1: critic task only
+  }
   forward_hidden(shape, L, params, x, N, w, 0, 1, s);
   CATPPO_CHECK_LAUNCH(ctx);
   const int nl = shape->n_hidden;
@@ -819,35 +884,51 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
                      b_returns_n, b_values_n, mb_inds, M, L.obs_pad, A, w.xmb, w.act, w.scal, w.adv_part);
   CATPPO_CHECK_LAUNCH(ctx);
 
-  // 2. hidden layers forward, both nets per launch
-  forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s);
-  CATPPO_CHECK_LAUNCH(ctx);
+  const int fv = fused_variant(shape);
+  const int rpt = fv ? fused_rows(fv) : 0;
+  if (rpt) {
+    // 2-3 (fused). forward chain, heads + losses, data-gradient chain: ONE launch, activations in LDS
+    nbh = (int)cdiv64(M, rpt);
+    FusedArgs f;
+    fill_fused(f, shape, L, params, w.xmb, M, w, true);
+    f.act = w.act, f.oldlogp = w.scal, f.adv = w.scal + M, f.ret_n = w.scal + 2 * M, f.val_n = w.scal + 3 * M;
+    f.adv_part = w.adv_part, f.n_adv_part = nbg;
+    f.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
+    f.vrms_mean = vrms_mean, f.vrms_var = vrms_var;
+    f.part_w = w.head_w, f.part_s = w.head_s;
+    f.hp = *hp;
+    if (int rc = launch_fused<true>(ctx, f, fv - 1, 2, s)) return rc;
+  } else {
+    // 2. hidden layers forward, both nets per launch
+    forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s);
+    CATPPO_CHECK_LAUNCH(ctx);
 
-  // 3. heads + losses + gradient w.r.t. last hidden pre-activations
-  HeadArgs g{};
-  g.Hc = w.H[0][nl - 1], g.Ha = w.H[1][nl - 1];
-  g.dZc = w.dZ[0][nl - 1], g.dZa = w.dZ[1][nl - 1];
-  g.W4c = params + L.off_w[0][nl], g.b4c = params + L.off_b[0][nl];
-  g.W4a = params + L.off_w[1][nl], g.b4a = params + L.off_b[1][nl];
-  g.logstd = params + L.off_logstd;
-  g.act = w.act, g.oldlogp = w.scal, g.adv = w.scal + M, g.ret_n = w.scal + 2 * M, g.val_n = w.scal + 3 * M;
-  g.adv_part = w.adv_part, g.n_adv_part = nbg;
-  g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
-  g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
-  g.part_w = w.head_w, g.part_s = w.head_s;
-  g.M = M, g.A = A, g.hp = *hp;
-  const size_t head_lds =
-      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
-  const int rc = dispatch_cpl(HL, [&](auto cpl) {
-    constexpr int CPL = decltype(cpl)::value;
-    auto kern = head_loss_kernel<CPL>;
-    if (head_lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)head_lds);
-    kern<<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
-  });
-  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
-  CATPPO_CHECK_LAUNCH(ctx);
+    // 3. heads + losses + gradient w.r.t. last hidden pre-activations
+    HeadArgs g{};
+    g.Hc = w.H[0][nl - 1], g.Ha = w.H[1][nl - 1];
+    g.dZc = w.dZ[0][nl - 1], g.dZa = w.dZ[1][nl - 1];
+    g.W4c = params + L.off_w[0][nl], g.b4c = params + L.off_b[0][nl];
+    g.W4a = params + L.off_w[1][nl], g.b4a = params + L.off_b[1][nl];
+    g.logstd = params + L.off_logstd;
+    g.act = w.act, g.oldlogp = w.scal, g.adv = w.scal + M, g.ret_n = w.scal + 2 * M, g.val_n = w.scal + 3 * M;
+    g.adv_part = w.adv_part, g.n_adv_part = nbg;
+    g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
+    g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
+    g.part_w = w.head_w, g.part_s = w.head_s;
+    g.M = M, g.A = A, g.hp = *hp;
+    const size_t head_lds =
+        sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
+    const int rc = dispatch_cpl(HL, [&](auto cpl) {
+      constexpr int CPL = decltype(cpl)::value;
+      auto kern = head_loss_kernel<CPL>;
+      if (head_lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)head_lds);
+      kern<<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
+    });
+    if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
+    CATPPO_CHECK_LAUNCH(ctx);
+  }
 
   // 4. backward through the hidden layers; split-K partials for every weight gradient
   SegTable segs{};
@@ -916,8 +997,8 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     }
     hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);
     CATPPO_CHECK_LAUNCH(ctx);
-    if (l > 0) {
-      // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
+    if (l > 0 && !rpt) {
+      // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})   (the fused kernel already produced it)
       Params px{};
       px.nets = 2;
       px.splits = 1;

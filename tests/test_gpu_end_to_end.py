@@ -127,3 +127,48 @@ def test_env_sharded_code_path_on_one_gpu():
                PYTHONPATH=os.pathsep.join([root, os.path.join(root, "constraints-as-terminations_amd")]))
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("variant", ["1", "2"])
+def test_fused_row_tile_kernel_variants(variant):
+    """CATPPO_FUSED=1|2 (opt-in, measured slower than the layer-wise path): forward chain + heads + losses +
+    data-gradient chain in one launch must pass the same minibatch / policy parity tests."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CATPPO_FUSED=variant)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu",
+                        "-q", "-p", "no:cacheprovider", "-k", "minibatch or policy"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "7 passed" in r.stdout, r.stdout[-500:]
+
+
+def test_train_and_play_entry_points(tmp_path):
+    """scripts/clean_rl/train.py with the reference's flags, checkpoint written with the reference's naming,
+    then scripts/clean_rl/play.py loads it and rolls the policy out."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (like the reference, --experiment_name is accepted but the log directory follows the task's cfg)
+    common = ["--task=Isaac-Velocity-CaT-Flat-Solo12-v0", "--headless", "--num_envs", "256"]
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts/clean_rl/train.py"), *common, "--num_iterations", "4",
+                        "--seed", "3", "agent.save_interval=2", "agent.minibatch_size=2048", "env.synthetic.stream_steps=32"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Starting training for 4 steps" in r.stdout and "Saved model" in r.stdout
+    runs = os.listdir(tmp_path / "logs" / "clean_rl" / "solo12_flat")
+    assert len(runs) == 1
+    run = tmp_path / "logs" / "clean_rl" / "solo12_flat" / runs[0]
+    files = sorted(os.listdir(run))
+    assert "model_1.pt" in files and "model_3.pt" in files          # (iteration + 1) % save_interval == 0
+    assert os.path.exists(run / "params" / "agent.yaml") and os.path.exists(run / "params" / "env.pkl")
+    sd = torch.load(run / "model_3.pt", map_location="cpu")
+    assert len(sd) == 23 and sd["actor_mean.0.weight"].shape == (512, 45) and float(sd["obs_rms.count"]) > 1
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts/clean_rl/play.py"), *common, "--video_length", "8"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "model_3.pt" in r.stdout and "mean reward per step" in r.stdout

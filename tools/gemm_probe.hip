@@ -18,10 +18,11 @@ using gemm::Params;
     }                                                                          \
   } while (0)
 
+static size_t g_extra_lds = 0;   // pad the dynamic LDS request to force fewer workgroups per CU
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = 16>
 float run(const Params& p, int reps) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);
-  constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC, BKT>();
+  const size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC, BKT>() + g_extra_lds;
   if (lds > 64 * 1024)
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, BKT>),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -109,5 +110,16 @@ int main(int argc, char** argv) {
     printf("%s  128x128: %7.1f us %6.1f TF   64x64: %7.1f us %6.1f TF   BK32 128x128: %7.1f us %6.1f TF  64x64: %7.1f us %6.1f TF\n",
            s.name, a, fl / a / 1e6, b, fl / b / 1e6, c, fl / c / 1e6, d, fl / d / 1e6);
   }
+  // occupancy experiment: the same 128x128 forward GEMM with 1 workgroup (4 waves) per CU
+  for (size_t extra : {(size_t)0, (size_t)60 * 1024, (size_t)110 * 1024}) {
+    g_extra_lds = extra;
+    Params p{};
+    p.nets = 2, p.splits = 1, p.I = M, p.J = 256, p.Kc = 512, p.lda = 512, p.ldb = 512, p.ldc = 256;
+    for (int n = 0; n < 2; ++n) p.op[n] = {X[n], W[n], Y[n], bias[n], nullptr, nullptr};
+    const double fl = 2.0 * M * 256 * 512 * 2;
+    float a = run<128, 128, true, true, gemm::EPI_BIAS_ELU>(p, reps);
+    printf("occupancy probe fwd J=256 K=512 128x128, extra LDS %3zu KB: %7.1f us %6.1f TF\n", extra / 1024, a, fl / a / 1e6);
+  }
+  g_extra_lds = 0;
   return 0;
 }
