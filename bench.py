@@ -214,6 +214,7 @@ def main():
         M = 16384
         flops_per_launch = 3 * 2 * macs * M                       # fwd + bwd = 3x fwd, per minibatch
         ach = flops_per_launch / grad_us / 1e6
+        traffic = pmc_traffic(a.workload)
         out = {
             "metric": "env-steps/s CaT-PPO iteration (rollout + GAE + PPO update)", "value": value,
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -224,10 +225,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad (gather, 2x3 grouped fp32-MFMA GEMM launches fwd, "
                          "head+loss, split-K dW + dX GEMMs, partial reductions) per 16384-sample minibatch",
                          "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(a.workload), "avg_launch_us": grad_us,
+                         "traffic": traffic, "avg_launch_us": grad_us,
                          "flops_per_launch": flops_per_launch,
-                         "traffic_source": "profiles/r1_pmc_traffic_cfg2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                           "of this command, FETCH x2 gfx950 correction)"},
+                         "traffic_source": None if traffic is None else
+                         f"profiles/r1_pmc_traffic_{a.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
+                         "of this command, FETCH x2 gfx950 correction)"},
             "gae": {"config_size": gae_roofline(nat, w["num_steps"], w["num_envs"]),
                     "hbm_sweep": [gae_roofline(nat, 24, 1 << 20, 20), gae_roofline(nat, 48, 1 << 22, 10)],
                     "bound": "hbm", "peak_GBps": HBM_PEAK_GBPS, "bytes_per_env_step": 24},

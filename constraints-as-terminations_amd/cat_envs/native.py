@@ -60,7 +60,7 @@ _SIGNATURES = {
     "catppo_cat_colmax": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "catppo_cat_apply": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "catppo_cat_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp]),
+    "catppo_cat_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "catppo_cat_terms": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32,
                                    _vp]),
     "catppo_env_pre_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
@@ -229,11 +229,11 @@ class Native:
         self._ok(self.lib.catppo_cat_terms(self.h, arr, len(arr), int(n_envs), _p(forces), fstride, int(H), int(B),
                                            _p(command), cld, _p(cstr), cstr.shape[1], self._stream()))
 
-    def cat_reset(self, ep_viol, ep_prob, episode_length, mask, out):
+    def cat_reset(self, ep_viol, ep_prob, episode_length, mask, out, prev=None):
         n_terms, N = ep_viol.shape
         _chk(episode_length, torch.int64, "episode_length")
         self._ok(self.lib.catppo_cat_reset(self.h, _p(ep_viol), _p(ep_prob), _p(episode_length), _p(mask), n_terms,
-                                           N, _p(out), self._stream()))
+                                           N, _p(prev), _p(out), self._stream()))
 
     # ------------------------------------------------------------------ env bookkeeping
     def env_pre_step(self, action_in, action, prev_action, episode_length, max_len, hard_reset, reward_src,

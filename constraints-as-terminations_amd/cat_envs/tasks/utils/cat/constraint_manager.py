@@ -217,9 +217,9 @@ class ConstraintManager(ManagerBase):
                     mask[ids.to(self._device).long()] = True
             nat = native.get(self._device)
             prev, self._log_pos = self._log_pos, (self._log_pos + 1) % self.LOG_RING
-            out = self._log_ring[self._log_pos]
-            out.copy_(self._log_ring[prev])      # "no env selected" keeps the previous values
-            nat.cat_reset(self._ep_viol, self._ep_prob, self._env.episode_length_buf, mask, out)
+            out = self._log_ring[self._log_pos]      # "no env selected" copies the previous slot (in-kernel)
+            nat.cat_reset(self._ep_viol, self._ep_prob, self._env.episode_length_buf, mask, out,
+                          prev=self._log_ring[prev])
             if self._log_views is None:
                 self._log_views = []
                 for r in range(self.LOG_RING):

@@ -169,17 +169,19 @@ __global__ __launch_bounds__(kThreads) void cat_finish(
   }
 }
 
-// one block per term: masked means of sums/len (fp64 accumulation, fixed order), then zero the rows
-__global__ __launch_bounds__(kThreads) void cat_reset_stats(float* __restrict__ ep_viol, float* __restrict__ ep_prob,
-                                                            const int64_t* __restrict__ ep_len,
-                                                            const uint8_t* __restrict__ mask, int64_t N,
-                                                            float* __restrict__ out) {
-  __shared__ double s_a[kThreads], s_b[kThreads], s_n[kThreads];
+// one 1024-thread block per term: masked means of sums/len (fp64 accumulation, fixed order), then zero
+// the rows.  N = 4096 is four elements per thread: the kernel is a single round of loads.
+constexpr int kResetThreads = 1024;
+__global__ __launch_bounds__(kResetThreads) void cat_reset_stats(float* __restrict__ ep_viol, float* __restrict__ ep_prob,
+                                                                 const int64_t* __restrict__ ep_len,
+                                                                 const uint8_t* __restrict__ mask, int64_t N,
+                                                                 const float* __restrict__ prev, float* __restrict__ out) {
+  __shared__ double s_a[kResetThreads / 64], s_b[kResetThreads / 64], s_n[kResetThreads / 64];
   const int t = blockIdx.x;
   float* v = ep_viol + (int64_t)t * N;
   float* p = ep_prob + (int64_t)t * N;
   double a = 0.0, b = 0.0, n = 0.0;
-  for (int64_t i = threadIdx.x; i < N; i += kThreads) {
+  for (int64_t i = threadIdx.x; i < N; i += kResetThreads) {
     if (mask == nullptr || mask[i]) {
       const float L = (float)ep_len[i];
       a += (double)(v[i] / L);
@@ -189,19 +191,24 @@ __global__ __launch_bounds__(kThreads) void cat_reset_stats(float* __restrict__ 
       p[i] = 0.0f;
     }
   }
-  s_a[threadIdx.x] = a, s_b[threadIdx.x] = b, s_n[threadIdx.x] = n;
-  __syncthreads();
-  for (int w = kThreads / 2; w >= 1; w >>= 1) {
-    if (threadIdx.x < w) {
-      s_a[threadIdx.x] += s_a[threadIdx.x + w];
-      s_b[threadIdx.x] += s_b[threadIdx.x + w];
-      s_n[threadIdx.x] += s_n[threadIdx.x + w];
-    }
-    __syncthreads();
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    a += __shfl_xor(a, m, 64);
+    b += __shfl_xor(b, m, 64);
+    n += __shfl_xor(n, m, 64);
   }
-  if (threadIdx.x == 0 && s_n[0] > 0.0) {
-    out[2 * t] = (float)(s_a[0] / s_n[0]) * 100.0f;
-    out[2 * t + 1] = (float)(s_b[0] / s_n[0]);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_a[wave] = a, s_b[wave] = b, s_n[wave] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kResetThreads / 64; ++w) a += s_a[w], b += s_b[w], n += s_n[w];
+    if (n > 0.0) {
+      out[2 * t] = (float)(a / n) * 100.0f;
+      out[2 * t + 1] = (float)(b / n);
+    } else if (prev != nullptr) {   // nobody reset: keep the previous log values (reference keeps extras["log"])
+      out[2 * t] = prev[2 * t];
+      out[2 * t + 1] = prev[2 * t + 1];
+    }
   }
 }
 
@@ -302,11 +309,12 @@ extern "C" int catppo_cat_step(catppo_ctx* ctx, const float* cstr, int64_t N, in
 }
 
 extern "C" int catppo_cat_reset(catppo_ctx* ctx, float* ep_viol, float* ep_prob, const int64_t* episode_length,
-                                const uint8_t* mask, int n_terms, int64_t N, float* out, void* stream) {
+                                const uint8_t* mask, int n_terms, int64_t N, const float* prev, float* out,
+                                void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, ep_viol && ep_prob && episode_length && out && n_terms >= 1 && N >= 1);
-  hipLaunchKernelGGL(cat_reset_stats, dim3(n_terms), dim3(kThreads), 0, static_cast<hipStream_t>(stream), ep_viol,
-                     ep_prob, episode_length, mask, N, out);
+  hipLaunchKernelGGL(cat_reset_stats, dim3(n_terms), dim3(kResetThreads), 0, static_cast<hipStream_t>(stream), ep_viol,
+                     ep_prob, episode_length, mask, N, prev, out);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

@@ -93,12 +93,12 @@ int catppo_cat_apply(catppo_ctx* ctx, const float* cstr, int64_t N, int K,
  * (uint8/bool [N]; NULL = all envs), then zero their accumulators:
  *   out[2t]   = mean_i(ep_viol[t,i] / len_i) * 100      "Episode_Constraint_violation/<term>"
  *   out[2t+1] = mean_i(ep_prob[t,i] / len_i)            "Episode_Constraint_probability/<term>"
- * If no env is selected `out` keeps its previous content (the reference keeps the last log
- * dict in env.extras until the next reset).  episode_length: int64 [N] (IsaacLab's
+ * If no env is selected `out` receives `prev` (may be NULL: `out` untouched) - the reference keeps the
+ * last log dict in env.extras until the next reset.  episode_length: int64 [N] (IsaacLab's
  * episode_length_buf); a zero length gives NaN/inf exactly like the reference's first reset.
  * replaces: cat/constraint_manager.py:190-211. */
 int catppo_cat_reset(catppo_ctx* ctx, float* ep_viol, float* ep_prob, const int64_t* episode_length,
-                     const uint8_t* mask, int n_terms, int64_t N, float* out, void* stream);
+                     const uint8_t* mask, int n_terms, int64_t N, const float* prev, float* out, void* stream);
 
 /* Solo12 constraint terms evaluated straight from sim-state tensors into the cstr matrix.
  * `desc` is a host array of n_terms descriptors (see catppo_term_desc).

@@ -1,9 +1,9 @@
 """Load a CleanRL checkpoint into ``Agent`` and roll the policy out (reference: scripts/clean_rl/play.py).
 
 Checkpoints written by ``PPO()`` (``model_<it>.pt``, the reference's 23-key ``state_dict``) load
-here and in the reference's play.py alike.  ONNX / TorchScript export needs the torch-op module
-graph and is listed as "next" in SURVEY 8f; this script covers checkpoint discovery, loading and
-the deterministic roll-out on the device kernels.
+here and in the reference's play.py alike.  Like the reference (play.py:107-135) the script writes
+``<run>/exported/model.onnx`` and ``<run>/exported/model.pt`` (deterministic policy with the frozen
+observation normaliser) before rolling the policy out on the device kernels.
 """
 import argparse
 import os
@@ -64,6 +64,12 @@ def main(argv=None):
     actor = Agent(env, hidden=tuple(agent_cfg.hidden))
     actor.load_state_dict(torch.load(resume_path, map_location=actor.flat.device))
     actor.eval()
+
+    from cat_envs.tasks.utils.cleanrl.export import export_policy
+    exported = export_policy(actor.state_dict(), os.path.join(os.path.dirname(resume_path), "exported"))
+    print(f"[INFO] Exported ONNX model to {exported['onnx']}")
+    print(f"[INFO] Exported .pt model to {exported['jit']}")
+
     obs = env.reset()[0]["policy"]
     ret = 0.0
     for _ in range(args_cli.video_length):
