@@ -69,6 +69,10 @@ _SIGNATURES = {
     "catppo_adv_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "catppo_adv_stats": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
+    "catppo_gae_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
+                                _vp]),
+    "catppo_adv_normalize": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "catppo_value_bootstrap": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rms_merge": (C.c_int, [_vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
     "catppo_rms_update": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
@@ -269,6 +273,41 @@ class Native:
         self._ok(self.lib.catppo_gae(self.h, _p(rewards), _p(values), _p(dones), _p(true_dones), _p(next_value),
                                      _p(next_done), _p(next_true_done), f32(gamma), f32(gamma * gae_lambda),
                                      _p(advantages), _p(returns), T, N, self._stream()))
+
+    GAE_CLEANRL, GAE_RL_GAMES, GAE_SKRL = 0, 1, 2
+
+    def gae_rl_games(self, fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma, tau, advantages, returns):
+        """rl_games discount_values with float dones ((T,N) planes, time major)"""
+        T, N = mb_rewards.shape
+        for n, t in (("fdones", fdones), ("last_values", last_values), ("mb_fdones", mb_fdones),
+                     ("mb_values", mb_values), ("mb_rewards", mb_rewards), ("advantages", advantages),
+                     ("returns", returns)):
+            _chk(t, torch.float32, n)
+        self._ok(self.lib.catppo_gae_ex(self.h, self.GAE_RL_GAMES, _p(mb_rewards), _p(mb_values), _p(mb_fdones), None,
+                                        _p(last_values), _p(fdones), None, f32(gamma), f32(gamma * tau),
+                                        _p(advantages), _p(returns), T, N, self._stream()))
+
+    def gae_skrl(self, rewards, dones, values, last_values, discount_factor, lambda_coefficient, advantages,
+                 returns):
+        """skrl compute_gae recurrence (raw advantages; normalise with adv_normalize)"""
+        T, N = rewards.shape
+        for n, t in (("rewards", rewards), ("dones", dones), ("values", values), ("last_values", last_values),
+                     ("advantages", advantages), ("returns", returns)):
+            _chk(t, torch.float32, n)
+        self._ok(self.lib.catppo_gae_ex(self.h, self.GAE_SKRL, _p(rewards), _p(values), _p(dones), None,
+                                        _p(last_values), None, None, f32(discount_factor), f32(lambda_coefficient),
+                                        _p(advantages), _p(returns), T, N, self._stream()))
+
+    def adv_normalize(self, advantages, out, stats=None):
+        self._ok(self.lib.catppo_adv_normalize(self.h, _p(_chk(advantages, torch.float32, "advantages")),
+                                               advantages.numel(), _p(_chk(out, torch.float32, "out")), _p(stats),
+                                               self._stream()))
+
+    def value_bootstrap(self, rewards, values, time_outs, gamma):
+        _chk(time_outs, torch.uint8, "time_outs")
+        self._ok(self.lib.catppo_value_bootstrap(self.h, _p(_chk(rewards, torch.float32, "rewards")),
+                                                 _p(_chk(values, torch.float32, "values")), _p(time_outs),
+                                                 f32(gamma), rewards.numel(), self._stream()))
 
     # ------------------------------------------------------------------ running mean / std
     def rms_update(self, x, n_rows, dim, ldx, mean, var, count):

@@ -1,0 +1,5 @@
+"""Return computation of the reference's skrl front end on the HIP kernels.
+skrl (agent base class, models, memories, KL-adaptive scheduler) is third-party and out of scope; the
+CaT-specific part - ``compute_gae`` with float ``not_dones`` and whole-batch advantage normalisation
+(skrl/ppo.py:397-442) - is provided with the same signature."""
+from .returns import compute_gae  # noqa: F401

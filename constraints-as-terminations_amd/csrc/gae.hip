@@ -37,7 +37,12 @@ __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
   }
 }
 
-template <int VEC>
+// KIND selects the recurrence (all three are the reference's float-done variants):
+//   0 CleanRL   (cleanrl/ppo.py:255-276)     d = done_{t+1}, time-out channel td_{t+1}
+//   1 rl_games  (rl_games/cat_common.py:96-103 -> A2CBase.discount_values with float fdones): the CleanRL
+//               recurrence without the time-out channel (tn == 1 exactly, one plane less to read)
+//   2 skrl      (skrl/ppo.py:397-442)        d = done_t:  A_t = (r_t - v_t) + (g*nd_t) * (v_{t+1} + l*A_{t+1})
+template <int VEC, int KIND>
 __global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, const float* __restrict__ val,
                                                 const float* __restrict__ done, const float* __restrict__ tdone,
                                                 const float* __restrict__ next_val,
@@ -49,8 +54,8 @@ __global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, c
   if (env >= N) return;
   float vnext[VEC], dn[VEC], tdn[VEC], last[VEC];
   load<VEC>(next_val + env, vnext);
-  load<VEC>(next_done + env, dn);
-  load<VEC>(next_tdone + env, tdn);
+  if constexpr (KIND != 2) load<VEC>(next_done + env, dn);
+  if constexpr (KIND == 0) load<VEC>(next_tdone + env, tdn);
 #pragma unroll
   for (int k = 0; k < VEC; ++k) last[k] = 0.0f;
 
@@ -60,41 +65,71 @@ __global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, c
     float r[VEC], v[VEC], d[VEC], td[VEC], a[VEC], q[VEC];
     load<VEC>(rew + off, r);
     load<VEC>(val + off, v);
-    load<VEC>(done + off, d);     // consumed by step t-1
-    load<VEC>(tdone + off, td);
+    load<VEC>(done + off, d);     // KIND 0/1: consumed by step t-1;  KIND 2: by this step
+    if constexpr (KIND == 0) load<VEC>(tdone + off, td);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-      const float nn = 1.0f - dn[k];
-      const float tn = 1.0f - tdn[k];
-      float x = gamma * vnext[k];   // GAMMA * nextvalues
-      x = x * nn;                   //   * nextnonterminal
-      x = x * tn;                   //   * true_nextnonterminal
-      float delta = r[k] + x;
-      delta = delta - v[k];
-      float c = gl * nn;            // (GAMMA*GAE_LAMBDA) * nextnonterminal
-      c = c * tn;
-      c = c * last[k];
-      last[k] = delta + c;
+      if constexpr (KIND == 2) {
+        const float nd = 1.0f - d[k];
+        const float g = gamma * nd;         // discount_factor * not_dones[i]
+        float c = gl * last[k];             // lambda_coefficient * advantage
+        c = vnext[k] + c;                   // next_values + ...
+        c = g * c;
+        const float e = r[k] - v[k];        // rewards[i] - values[i]
+        last[k] = e + c;
+      } else {
+        const float nn = 1.0f - dn[k];
+        float x = gamma * vnext[k];   // GAMMA * nextvalues
+        x = x * nn;                   //   * nextnonterminal
+        float c = gl * nn;            // (GAMMA*GAE_LAMBDA) * nextnonterminal
+        if constexpr (KIND == 0) {
+          const float tn = 1.0f - tdn[k];
+          x = x * tn;                 //   * true_nextnonterminal
+          c = c * tn;
+          tdn[k] = td[k];
+        }
+        float delta = r[k] + x;
+        delta = delta - v[k];
+        c = c * last[k];
+        last[k] = delta + c;
+        dn[k] = d[k];
+      }
       a[k] = last[k];
       q[k] = last[k] + v[k];        // returns = advantages + values
       vnext[k] = v[k];
-      dn[k] = d[k];
-      tdn[k] = td[k];
     }
     store<VEC>(adv + off, a);
     store<VEC>(ret + off, q);
   }
 }
 
+template <int KIND>
+void launch_gae(bool wide, const float* rewards, const float* values, const float* dones, const float* true_dones,
+                const float* next_value, const float* next_done, const float* next_true_done, float gamma, float gl,
+                float* advantages, float* returns, int T, int64_t N, hipStream_t s) {
+  if (wide) {
+    const int block = 256;
+    gae_scan<4, KIND><<<dim3((unsigned)cdiv64(N / 4, block)), dim3(block), 0, s>>>(
+        rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gl, advantages, returns, T, N);
+  } else {
+    // small N: one wave per block so that 4096 envs already spread over 64 CUs
+    const int block = N >= 65536 ? 256 : 64;
+    gae_scan<1, KIND><<<dim3((unsigned)cdiv64(N, block)), dim3(block), 0, s>>>(
+        rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gl, advantages, returns, T, N);
+  }
+}
+
 }  // namespace
 
-extern "C" int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,
-                          const float* true_dones, const float* next_value, const float* next_done,
-                          const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
-                          float* returns, int T, int64_t N, void* stream) {
+extern "C" int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values,
+                             const float* dones, const float* true_dones, const float* next_value,
+                             const float* next_done, const float* next_true_done, float gamma, float gamma_lambda,
+                             float* advantages, float* returns, int T, int64_t N, void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  CATPPO_CHECK_ARG(ctx, rewards && values && dones && true_dones && next_value && next_done && next_true_done);
-  CATPPO_CHECK_ARG(ctx, advantages && returns);
+  CATPPO_CHECK_ARG(ctx, kind >= CATPPO_GAE_CLEANRL && kind <= CATPPO_GAE_SKRL);
+  CATPPO_CHECK_ARG(ctx, rewards && values && dones && next_value && advantages && returns);
+  CATPPO_CHECK_ARG(ctx, kind == CATPPO_GAE_SKRL || next_done != nullptr);
+  CATPPO_CHECK_ARG(ctx, kind != CATPPO_GAE_CLEANRL || (true_dones && next_true_done));
   CATPPO_CHECK_ARG(ctx, T >= 1 && N >= 1);
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
@@ -104,19 +139,27 @@ extern "C" int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* va
                     aligned16(values) && aligned16(dones) && aligned16(true_dones) && aligned16(next_value) &&
                     aligned16(next_done) && aligned16(next_true_done) && aligned16(advantages) &&
                     aligned16(returns);
-  if (wide) {
-    const int block = 256;
-    const int64_t lanes = N / 4;
-    hipLaunchKernelGGL(gae_scan<4>, dim3((unsigned)cdiv64(lanes, block)), dim3(block), 0, s, rewards, values, dones,
-                       true_dones, next_value, next_done, next_true_done, gamma, gamma_lambda, advantages, returns,
-                       T, N);
-  } else {
-    // small N: one wave per block so that 4096 envs already spread over 64 CUs
-    const int block = N >= 65536 ? 256 : 64;
-    hipLaunchKernelGGL(gae_scan<1>, dim3((unsigned)cdiv64(N, block)), dim3(block), 0, s, rewards, values, dones,
-                       true_dones, next_value, next_done, next_true_done, gamma, gamma_lambda, advantages, returns,
-                       T, N);
+  switch (kind) {
+    case CATPPO_GAE_CLEANRL:
+      launch_gae<0>(wide, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma,
+                    gamma_lambda, advantages, returns, T, N, s);
+      break;
+    case CATPPO_GAE_RL_GAMES:
+      launch_gae<1>(wide, rewards, values, dones, nullptr, next_value, next_done, nullptr, gamma, gamma_lambda,
+                    advantages, returns, T, N, s);
+      break;
+    default:
+      launch_gae<2>(wide, rewards, values, dones, nullptr, next_value, nullptr, nullptr, gamma, gamma_lambda,
+                    advantages, returns, T, N, s);
   }
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
+}
+
+extern "C" int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,
+                          const float* true_dones, const float* next_value, const float* next_done,
+                          const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
+                          float* returns, int T, int64_t N, void* stream) {
+  return catppo_gae_ex(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
+                       next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
 }

@@ -197,6 +197,40 @@ int launch_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ld
   return CATPPO_OK;
 }
 
+// whole-batch advantage normalisation (skrl/ppo.py:436: (A - A.mean()) / (A.std() + 1e-8), unbiased std):
+// every block folds the <=128 fp64 partial moment rows in the same fixed order, so all blocks hold the
+// same mean / std, then normalises its slice.
+__global__ __launch_bounds__(kThreads) void adv_normalize_kernel(const float* __restrict__ x, int64_t n,
+                                                                 const double* __restrict__ partial, int nblk,
+                                                                 float* __restrict__ out,
+                                                                 float* __restrict__ stats) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += partial[2 * b];
+    s2 += partial[2 * b + 1];
+  }
+  const double cnt = (double)n;
+  const double mean_d = s1 / cnt;
+  double var = n > 1 ? (s2 - cnt * mean_d * mean_d) / (cnt - 1.0) : __builtin_nan("");
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d;
+  const float den = (float)sqrt(var) + 1e-8f;
+  if (stats != nullptr && blockIdx.x == 0 && threadIdx.x == 0) stats[0] = mean, stats[1] = den;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+    const float c = x[i] - mean;
+    out[i] = c / den;
+  }
+}
+
+__global__ void value_bootstrap_kernel(float* __restrict__ rew, const float* __restrict__ val,
+                                       const uint8_t* __restrict__ to, float gamma, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float b = gamma * val[i];                  // self.gamma * res_dict["values"]
+  b = b * (to[i] ? 1.0f : 0.0f);             //   * time_outs.float()
+  rew[i] = rew[i] + b;                       // shaped_rewards += ...
+}
+
 }  // namespace
 
 extern "C" int catppo_rms_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, double* sums,
@@ -254,6 +288,38 @@ extern "C" int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, 
   if (nblk > 2048) nblk = 2048;
   hipLaunchKernelGGL(rms_normalize, dim3((unsigned)nblk), dim3(kThreads), sizeof(float) * 2 * D,
                      static_cast<hipStream_t>(stream), x, N, D, ldx, mean, var, eps, out, ldo);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_adv_normalize(catppo_ctx* ctx, const float* advantages, int64_t n, float* out, float* stats,
+                                    void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, advantages && out && n >= 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rows_per_block = kThreads * 16;
+  int nblk = (int)cdiv64(n, rows_per_block);
+  if (nblk > 128) nblk = 128;
+  WsCarver ws(ctx);
+  double* partial = ws.take<double>((uint64_t)nblk * 2);
+  CATPPO_NEED_WS(ctx, partial);
+  hipLaunchKernelGGL(rms_moments_partial, dim3(nblk), dim3(kThreads), 0, s, advantages, n, 1, (int64_t)1, rows_per_block,
+                     partial);
+  CATPPO_CHECK_LAUNCH(ctx);
+  int64_t nb = cdiv64(n, kThreads * 4);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(adv_normalize_kernel, dim3((unsigned)nb), dim3(kThreads), 0, s, advantages, n,
+                     (const double*)partial, nblk, out, stats);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_value_bootstrap(catppo_ctx* ctx, float* rewards, const float* values, const uint8_t* time_outs,
+                                      float gamma, int64_t N, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, rewards && values && time_outs && N >= 1);
+  hipLaunchKernelGGL(value_bootstrap_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rewards, values, time_outs, gamma, N);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

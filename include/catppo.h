@@ -171,6 +171,31 @@ int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const
                const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
                float* returns, int T, int64_t N, void* stream);
 
+/* The float-done recurrences of the reference's other two trainers, same buffers and launch shape:
+ *   CATPPO_GAE_RL_GAMES  rl_games/cat_common.py:96-103 -> rl_games A2CBase.discount_values(fdones float):
+ *       the CleanRL recurrence without the time-out channel (true_dones / next_true_done ignored, may
+ *       be NULL); gamma_lambda = fl32(gamma*tau).  18 B per env-step.
+ *   CATPPO_GAE_SKRL      skrl/ppo.py:397-442 compute_gae with `not_dones = 1 - dones`:
+ *       A_t = fl(fl(r_t - v_t) + fl(fl(gamma*(1-d_t)) * fl(v_{t+1} + fl(lambda*A_{t+1}))));
+ *       `dones` is indexed at t (not t+1), next_done / true_dones unused (may be NULL) and the
+ *       `gamma_lambda` argument carries lambda itself.  18 B per env-step.
+ * catppo_gae(...) == catppo_gae_ex(CATPPO_GAE_CLEANRL, ...). */
+typedef enum { CATPPO_GAE_CLEANRL = 0, CATPPO_GAE_RL_GAMES = 1, CATPPO_GAE_SKRL = 2 } catppo_gae_kind;
+int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values, const float* dones,
+                  const float* true_dones, const float* next_value, const float* next_done,
+                  const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
+                  float* returns, int T, int64_t N, void* stream);
+
+/* skrl whole-batch advantage normalisation (skrl/ppo.py:436): out = (A - mean(A)) / (std_unbiased(A) + 1e-8),
+ * moments in fp64 (deterministic); out may alias advantages; stats (NULL ok) receives {mean, std + 1e-8}. */
+int catppo_adv_normalize(catppo_ctx* ctx, const float* advantages, int64_t n, float* out, float* stats,
+                         void* stream);
+
+/* rl_games `value_bootstrap` (rl_games/cat_common.py:59-64): rewards_i += fl(fl(gamma*values_i) * time_out_i),
+ * in place, time_outs as uint8 {0,1}. */
+int catppo_value_bootstrap(catppo_ctx* ctx, float* rewards, const float* values, const uint8_t* time_outs,
+                           float gamma, int64_t N, void* stream);
+
 /* ---- RunningMeanStd ----------------------------------------------------------------------
  * x [N,D] with leading dimension ldx.  mean/var [D], count [1] fp32 state.
  *   catppo_rms_moments : sums[0:D] = sum_i x, sums[D:2D] = sum_i x^2   (fp64, deterministic)

@@ -186,6 +186,47 @@ def gae_numpy_exact(rew, val, done, tdone, nv, nd, ntd, gamma: float, gae_lambda
     return adv, (adv + val).astype(f)
 
 
+def gae_rl_games(fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma: float, tau: float):
+    """rl_games ``A2CBase.discount_values`` as called with float dones by the reference
+    (rl_games/cat_common.py:96-103).  rl_games (pinned 1.6.1 in the reference's setup) is NOT under
+    /root/reference, so this restates its published recurrence - PARITY UNPINNED against rl_games itself;
+    it is the CleanRL recurrence above without the time-out channel and is tested bit-equal to
+    ``gae(..., true_dones = 0)``, which the reference goldens do pin.  Returns (mb_advs, mb_returns)."""
+    T = mb_rewards.shape[0]
+    adv = torch.zeros_like(mb_rewards)
+    last = 0
+    for t in reversed(range(T)):
+        if t == T - 1:
+            nn_, nv = 1.0 - fdones, last_values
+        else:
+            nn_, nv = 1.0 - mb_fdones[t + 1], mb_values[t + 1]
+        delta = mb_rewards[t] + gamma * nv * nn_ - mb_values[t]
+        adv[t] = last = delta + gamma * tau * nn_ * last
+    return adv, adv + mb_values
+
+
+def value_bootstrap(rewards, values, time_outs, gamma: float):
+    """rl_games/cat_common.py:59-64: ``shaped_rewards += gamma * values * time_outs.float()``"""
+    return rewards + gamma * values * time_outs.float()
+
+
+def gae_skrl(rewards, dones, values, last_values, discount_factor: float = 0.99, lambda_coefficient: float = 0.95):
+    """skrl/ppo.py:397-442 ``compute_gae`` with the CaT float ``not_dones = 1 - dones``.
+    Returns (returns, normalised advantages, raw advantages).  Pinned by tests/golden/skrl_gae.npz, which
+    gen_golden.py produces by executing the reference's own nested function."""
+    advantage = 0
+    advantages = torch.zeros_like(rewards)
+    not_dones = 1 - dones
+    T = rewards.shape[0]
+    for i in reversed(range(T)):
+        nv = values[i + 1] if i < T - 1 else last_values
+        advantage = rewards[i] - values[i] + discount_factor * not_dones[i] * (nv + lambda_coefficient * advantage)
+        advantages[i] = advantage
+    returns = advantages + values
+    normed = (advantages - advantages.mean()) / (advantages.std() + 1e-8)
+    return returns, normed, advantages
+
+
 # ------------------------------------------------------------------ minibatch update
 def ppo_minibatch_loss(agent: AgentOracle, mb_obs, mb_actions, mb_logprobs, mb_adv,
                        mb_returns_n, mb_values_n, cfg):

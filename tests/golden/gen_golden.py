@@ -394,8 +394,35 @@ def run_ref_ppo(tag, seed, N, T, iters, mb, epochs, D=45, A=12, sub=1, keep_grad
     save(f"ppo_{tag}", **out)
 
 
+def gen_skrl_gae():
+    """Executes the reference's own nested ``compute_gae`` (skrl/ppo.py:397-442): the function node is lifted
+    out of ``PPO._update`` with ``ast`` at generation time (skrl itself is not installed, so the module cannot
+    be imported), its free variable ``last_values`` is supplied as a global.  Nothing but arrays is stored."""
+    import ast
+    src = open(os.path.join(R.REF_ROOT, "exts/cat_envs/cat_envs/tasks/utils/skrl/ppo.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "compute_gae")
+    mod = ast.Module(body=[fn], type_ignores=[])
+    out = {}
+    for tag, (T, N) in {"a": (24, 64), "b": (1, 5), "c": (48, 33)}.items():
+        rs = np.random.RandomState(700 + T)
+        rew = rs.uniform(0, 1.5, (T, N, 1)).astype(np.float32)
+        val = rs.standard_normal((T, N, 1)).astype(np.float32)
+        done = np.where(rs.uniform(size=(T, N, 1)) < 0.3, rs.uniform(0, 1, (T, N, 1)), 0.0).astype(np.float32)
+        done[rs.uniform(size=(T, N, 1)) < 0.02] = 1.0
+        last = rs.standard_normal((N, 1)).astype(np.float32)
+        ns = {"torch": torch, "last_values": torch.from_numpy(last)}
+        exec(compile(mod, "<reference skrl/ppo.py compute_gae>", "exec"), ns)
+        ret, adv = ns["compute_gae"](torch.from_numpy(rew), torch.from_numpy(done), torch.from_numpy(val),
+                                     torch.from_numpy(last), discount_factor=0.99, lambda_coefficient=0.95)
+        out.update({f"{tag}_rewards": rew, f"{tag}_values": val, f"{tag}_dones": done, f"{tag}_last_values": last,
+                    f"{tag}_returns": t2n(ret), f"{tag}_advantages": t2n(adv)})
+    save("skrl_gae", **out)
+
+
 def main():
     assert R.have_reference(), "needs /root/reference (build container only)"
+    if sys.argv[1:] == ["skrl_gae"]:      # regenerate one fixture without touching the others
+        return gen_skrl_gae()
     print("CaT streams")
     gen_cat("small", 101, 7, S.CAT_TERMS_SMALL, [0.25, 1.0, 0.25, 1.0, 0.5], 16,
             curriculum_at=8, reset_at={5, 11})
@@ -408,6 +435,7 @@ def main():
     gen_envfinish()
     gen_rms()
     gen_agent()
+    gen_skrl_gae()
     print("PPO() runs")
     run_ref_ppo("64x24", 201, N=64, T=24, iters=3, mb=512, epochs=5)
     run_ref_ppo("64x48", 202, N=64, T=48, iters=1, mb=1024, epochs=1, keep_grads=False)

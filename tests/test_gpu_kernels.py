@@ -474,3 +474,131 @@ def test_errors_are_loud(nat):
     with pytest.raises(RuntimeError):
         fresh.gae(a[:, 0].contiguous().view(1, -1), v.view(1, -1), v.view(1, -1), v.view(1, -1), v, v, v, 0.99, 0.95,
                   torch.zeros(1, 1 << 20), torch.zeros(1, 1 << 20, device="cuda"))  # CPU tensor rejected
+
+
+# ---- the other two trainers' float-done recurrences -----------------------------
+@pytest.mark.parametrize("T,N,seed", [(1, 1, 1), (24, 64, 2), (16, 4096, 3), (8, 131072, 4)])
+def test_gae_rl_games_variant_bit_exact(nat, T, N, seed):
+    """discount_values with float fdones == the CleanRL recurrence with no time-out channel"""
+    x = S.gae_inputs(seed, T, N)
+    d = {k: dev(v) for k, v in x.items()}
+    adv, ret = torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda")
+    nat.gae_rl_games(d["next_done"], d["next_value"], d["dones"], d["values"], d["rewards"], 0.99, 0.95, adv, ret)
+    torch.cuda.synchronize()
+    t = {k: torch.from_numpy(v) for k, v in x.items()}
+    a, r = PO.gae_rl_games(t["next_done"], t["next_value"], t["dones"], t["values"], t["rewards"], 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy(), a.numpy())
+    np.testing.assert_array_equal(ret.cpu().numpy(), r.numpy())
+    z = np.zeros_like(x["dones"])
+    a0, _ = PO.gae_numpy_exact(x["rewards"], x["values"], x["dones"], z, x["next_value"], x["next_done"], z[0], 0.99,
+                               0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy(), a0)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gae_skrl_variant_vs_reference_golden(nat, golden, tag):
+    """returns bit-exact, whole-batch normalised advantages within 2e-6 of the reference's compute_gae"""
+    from cat_envs.tasks.utils.skrl import compute_gae
+    g = golden("skrl_gae")
+    rew, val, done, last = (g[f"{tag}_{k}"] for k in ("rewards", "values", "dones", "last_values"))
+    ret, adv = compute_gae(dev(rew), dev(done), dev(val), dev(last), discount_factor=0.99, lambda_coefficient=0.95)
+    torch.cuda.synchronize()
+    assert ret.shape == rew.shape and adv.shape == rew.shape
+    np.testing.assert_array_equal(ret.cpu().numpy(), g[f"{tag}_returns"])
+    if rew.size > 1:
+        np.testing.assert_allclose(adv.cpu().numpy(), g[f"{tag}_advantages"], rtol=2e-6, atol=2e-6)
+    else:
+        assert np.isnan(adv.cpu().numpy()).all() and np.isnan(g[f"{tag}_advantages"]).all()   # std of one sample
+
+
+def test_gae_skrl_wide_path_and_normalize_stats(nat):
+    T, N = 8, 131072
+    x = S.gae_inputs(9, T, N)
+    d = {k: dev(v) for k, v in x.items()}
+    adv, ret = torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda")
+    nat.gae_skrl(d["rewards"], d["dones"], d["values"], d["next_value"], 0.99, 0.95, adv, ret)
+    t = {k: torch.from_numpy(v) for k, v in x.items()}
+    r0, n0, a0 = PO.gae_skrl(t["rewards"], t["dones"], t["values"], t["next_value"], 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy(), a0.numpy())
+    np.testing.assert_array_equal(ret.cpu().numpy(), r0.numpy())
+    stats = torch.zeros(2, device="cuda")
+    out = torch.empty_like(adv)
+    nat.adv_normalize(adv, out, stats)
+    a64 = a0.numpy().astype(np.float64)
+    np.testing.assert_allclose(stats.cpu().numpy(), [a64.mean(), a64.std(ddof=1) + 1e-8], rtol=1e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), n0.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_value_bootstrap_bit_exact(nat):
+    from cat_envs.tasks.utils.rl_games import bootstrap_time_outs, discount_values
+    rs = np.random.RandomState(3)
+    n = 4099
+    rew = rs.uniform(0, 1.5, (n, 1)).astype(np.float32)
+    val = rs.standard_normal((n, 1)).astype(np.float32)
+    to = rs.uniform(size=n) < 0.2
+    r = dev(rew)
+    bootstrap_time_outs(r, dev(val), dev(to), 0.99)
+    want = PO.value_bootstrap(torch.from_numpy(rew), torch.from_numpy(val), torch.from_numpy(to).unsqueeze(1), 0.99)
+    np.testing.assert_array_equal(r.cpu().numpy(), want.numpy())
+    # (T, N, 1) buffer layout of the rl_games experience buffer through discount_values
+    x = S.gae_inputs(5, 12, 100)
+    adv = discount_values(dev(x["next_done"]), dev(x["next_value"][:, None]), dev(x["dones"]),
+                          dev(x["values"][:, :, None]), dev(x["rewards"][:, :, None]), 0.99, 0.95)
+    t = {k: torch.from_numpy(v) for k, v in x.items()}
+    a, _ = PO.gae_rl_games(t["next_done"], t["next_value"], t["dones"], t["values"], t["rewards"], 0.99, 0.95)
+    assert adv.shape == (12, 100, 1)
+    np.testing.assert_array_equal(adv.cpu().numpy()[:, :, 0], a.numpy())
+
+
+# ---- BASELINE full sizes ------------------------------------------------------------------------------
+def test_cat_step_32768_envs_mixed_hard_soft_max_p(nat):
+    """config 5 size: 32768 envs x 13 terms (78 columns), hard (max_p = 1) and soft (0.1 / 0.25) terms mixed,
+    every matrix bit-exact against the oracle over 4 steps with a max_p curriculum change at step 2."""
+    terms, n = S.CAT_TERMS_SOLO12, 32768
+    K, nt = sum(w for _, w, _ in terms), len(S.CAT_TERMS_SOLO12)
+    stream = S.cat_stream(77, n, terms, 4)
+    rm, prob = torch.zeros(K, device="cuda"), torch.zeros(n, device="cuda")
+    viol, eprob = torch.zeros(nt, n, device="cuda"), torch.zeros(nt, n, device="cuda")
+    probs = torch.zeros(n, K, device="cuda")
+    orc = CO.ConstraintManagerOracle([t[0] for t in terms], n, tau=0.95, min_p=0.0)
+    for t in range(4):
+        max_p = [p if t < 2 else min(1.0, 2 * p) for p in S.CAT_MAXP_SOLO12]
+        _, off_c, dp = term_meta(terms, max_p, 0.0)
+        nat.cat_step(dev(pack_stream_step(stream[t], terms)), off_c, dp, 0.0, 0.95, t == 0, rm, prob, viol, eprob,
+                     probs=probs)
+        po = orc.compute(stream[t], {nm: mp for (nm, _, _), mp in zip(terms, max_p)})
+        np.testing.assert_array_equal(prob.cpu().numpy(), po)
+        np.testing.assert_array_equal(probs.cpu().numpy(), np.concatenate([orc.cat.probs[nm] for nm, _, _ in terms], 1))
+    assert (prob.cpu().numpy() == 1.0).any() and ((prob.cpu().numpy() > 0) & (prob.cpu().numpy() < 1)).any()
+
+
+def test_gae_full_size_slices_and_linearity(nat):
+    """N = 2^22 envs x T = 48 (the 4.8 GB roofline-sweep size): slices of envs (the recurrence is independent per
+    env) bit-exact against the oracle, and the whole result checked through a size-independent property:
+    with dones == 0 the advantages are linear in the rewards, A(r1 + r2, v) + A(0, v) == A(r1, v) + A(r2, v)
+    up to fp32 rounding."""
+    T, N = 48, 1 << 22
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda *s: torch.rand(*s, device="cuda", generator=g)  # noqa: E731
+    rew, val = mk(T, N) * 1.5, mk(T, N) * 2 - 1
+    done = torch.where(mk(T, N) < 0.3, mk(T, N), torch.zeros((), device="cuda"))
+    done = torch.where(mk(T, N) < 0.02, torch.ones((), device="cuda"), done)
+    td = (mk(T, N) < 0.01).float()
+    nv, nd, ntd = mk(N) * 2 - 1, done[0].clone(), td[0].clone()
+    adv, ret = torch.empty(T, N, device="cuda"), torch.empty(T, N, device="cuda")
+    nat.gae(rew, val, done, td, nv, nd, ntd, 0.99, 0.95, adv, ret)
+    for sl in (slice(0, 2048), slice(N // 2 - 1000, N // 2 + 1000), slice(N - 2048, N)):
+        c = lambda x: x[..., sl].cpu().numpy()  # noqa: E731
+        a, r = PO.gae_numpy_exact(c(rew), c(val), c(done), c(td), c(nv), c(nd), c(ntd), 0.99, 0.95)
+        np.testing.assert_array_equal(c(adv), a)
+        np.testing.assert_array_equal(c(ret), r)
+    assert bool((ret == adv + val).all())
+    z, zr = torch.zeros(T, N, device="cuda"), torch.zeros(N, device="cuda")
+    r2 = mk(T, N)
+    out = []
+    for r_ in (rew + r2, z, rew, r2):
+        a_ = torch.empty(T, N, device="cuda")
+        nat.gae(r_, val, z, z, nv, zr, zr, 0.99, 0.95, a_, ret)
+        out.append(a_)
+    err = (out[0] + out[1] - out[2] - out[3]).abs().max().item()
+    assert err < 2e-4, err
