@@ -186,6 +186,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   }
   __syncthreads();
 
+  // data gradient: the activation the epilogue multiplies with does not depend on the contraction; with one
+  // accumulator tile per wave (16 values per lane) fetch it now so its HBM latency hides behind the main loop
+  constexpr bool AUX_EARLY = EPI == EPI_MUL_DELU && TM * TN == 1;
+  float auxv[AUX_EARLY ? 16 : 1];
+  if constexpr (AUX_EARLY) {
+    const int gj = j0 + wn * WN + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int gi = i0 + wm * WM + (r & 3) + 8 * (r >> 2) + 4 * h;
+      auxv[r] = (gi < p.I && gj < p.J) ? op.aux[(int64_t)gi * p.ldaux + gj] : 0.0f;
+    }
+  }
+
   for (int s = 0; s < n_slabs; ++s) {
     const int cur = s & 1;
     if (s + 1 < n_slabs) gload(k_begin + (s + 1) * BK);
@@ -259,7 +272,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
             v = elu_f(v + bias);
 #endif
           } else if (EPI == EPI_MUL_DELU) {
-            const float hact = op.aux[(int64_t)gi * p.ldaux + gj];
+            float hact;
+            if constexpr (AUX_EARLY) {
+              hact = auxv[r];
+            } else {
+              hact = op.aux[(int64_t)gi * p.ldaux + gj];
+            }
             v = v * (hact > 0.0f ? 1.0f : hact + 1.0f);  // elu'(z) = 1 (z>0) | exp(z) = elu(z)+1
           }
 #ifdef GEMM_PROBE_NOSTORE

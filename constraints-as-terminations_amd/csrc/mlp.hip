@@ -67,8 +67,8 @@ struct MlpWs {
   double* adv_part;        // [nb_gather][2]
   float* H[2][CATPPO_MAX_HIDDEN];   // activations per net / hidden layer [M, h_l]
   float* dZ[2][CATPPO_MAX_HIDDEN];  // pre-activation gradients
-  float* wpart;            // split-K partial weight gradients (largest layer, both nets)
-  float* bpart;            // split-K partial bias gradients
+  float* wpart[CATPPO_MAX_HIDDEN];   // split-K partial weight gradients per layer (both nets)
+  float* bpart[CATPPO_MAX_HIDDEN];   // split-K partial bias gradients per layer
   float* head_w;           // [nb_head][(A+1)*HL]
   float* head_s;           // [nb_head][kHeadScalars]
   double* norm_part;       // [kNormBlocks]
@@ -78,15 +78,15 @@ constexpr int kHeadDiag = 8;
 constexpr int kNormBlocks = 256;
 inline int head_scalars(int A) { return 2 * A + 1 + kHeadDiag; }  // db4a[A], db4c, dlogstd[A], diag[8]
 
-constexpr int kMaxSplits = 64;
-
-int64_t max_wpart(const catppo_mlp_shape* s, const catppo_mlp_layout& L) {
-  int64_t m = 0;
-  for (int l = 0; l < s->n_hidden; ++l) {
-    const int64_t e = (int64_t)s->hidden[l] * L.in_dim[l];
-    m = e > m ? e : m;
-  }
-  return m;
+// split-K count cap: the partial sums are written once and re-read by the fold, so a layer may use as many
+// splits as keep its partials under ~8 MB (32 for a 256x256 layer, 64+ for the narrow first layer, whose
+// 8 tiles would otherwise leave most CUs with one latency-bound workgroup).
+constexpr int kMinSplitCap = 32, kMaxSplitCap = 128;
+inline int split_cap(int out, int in) {
+  const int64_t bytes_per_split = 2 * (int64_t)out * in * (int64_t)sizeof(float);
+  int64_t cap = (8 << 20) / bytes_per_split;
+  cap = cap < kMinSplitCap ? kMinSplitCap : cap;
+  return (int)(cap > kMaxSplitCap ? kMaxSplitCap : cap);
 }
 
 bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, bool training, char* base,
@@ -113,8 +113,12 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
   if (training) {
     for (int net = 0; net < 2; ++net)
       for (int l = 0; l < nl; ++l) w->dZ[net][l] = (float*)take(sizeof(float) * M * s->hidden[l]);
-    w->wpart = (float*)take(sizeof(float) * 2 * kMaxSplits * max_wpart(s, L));
-    w->bpart = (float*)take(sizeof(float) * 2 * kMaxSplits * 4096);
+    // one partial buffer per layer: all weight-gradient partials of a minibatch are folded by ONE launch
+    for (int l = 0; l < nl; ++l) {
+      const int cap = split_cap(s->hidden[l], L.in_dim[l]);
+      w->wpart[l] = (float*)take(sizeof(float) * 2 * cap * (int64_t)s->hidden[l] * L.in_dim[l]);
+      w->bpart[l] = (float*)take(sizeof(float) * 2 * cap * s->hidden[l]);
+    }
     w->head_w = (float*)take(sizeof(float) * nbh * (A + 1) * s->hidden[nl - 1]);
     w->head_s = (float*)take(sizeof(float) * nbh * head_scalars(A));
   }
@@ -942,7 +946,8 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   // gradient (split-K GEMM + fold of its partials) is forked to the side stream as soon as that
   // layer's dZ exists, and everything is joined before returning to the caller's stream order.
   // The split-K partial buffers are reused layer after layer; the side stream serialises them.
-  hipStream_t side = ctx->use_side ? ctx->side : s;
+  const bool fork = ctx->use_side;
+  hipStream_t side = fork ? ctx->side : s;
 #define CATPPO_HIP_OK(call)                                                                          \
   do {                                                                                               \
     hipError_t e__ = (call);                                                                         \
@@ -952,8 +957,10 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   for (int l = nl - 1; l >= 0; --l) {
     const int out = shape->hidden[l], in = L.in_dim[l];
     // dZ_l is complete on the main stream here: fork
-    CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
-    CATPPO_HIP_OK(hipStreamWaitEvent(side, ctx->ev_fork[l], 0));
+    if (fork) {
+      CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
+      CATPPO_HIP_OK(hipStreamWaitEvent(side, ctx->ev_fork[l], 0));
+    }
     // weight gradient: dW[out,in] = dZ^T . Xin      (contraction over the M rows)
     Params pw{};
     pw.nets = 2;
@@ -963,7 +970,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     int splits = 512 / (tiles > 0 ? tiles : 1);
     const int max_by_rows = (int)cdiv64(M, 4 * gemm::BK);
     if (splits > max_by_rows) splits = max_by_rows;
-    if (splits > 32) splits = 32;   // partial-sum traffic grows with the split count
+    if (splits > split_cap(out, in)) splits = split_cap(out, in);
     if (splits < 1) splits = 1;
     int per = (int)cdiv64(M, splits);
     per = (per + gemm::BK - 1) / gemm::BK * gemm::BK;
@@ -974,19 +981,18 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     for (int net = 0; net < 2; ++net) {
       pw.op[net].A = w.dZ[net][l];
       pw.op[net].B = l == 0 ? w.xmb : w.H[net][l - 1];
-      pw.op[net].C = w.wpart + (int64_t)net * out * in;
-      pw.op[net].dbias = w.bpart + (int64_t)net * splits * out;   // [net][split][out]
+      pw.op[net].C = w.wpart[l] + (int64_t)net * out * in;
+      pw.op[net].dbias = w.bpart[l] + (int64_t)net * splits * out;   // [net][split][out]
     }
     launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side);
     CATPPO_CHECK_LAUNCH(ctx);
-    segs.n = 0;
     for (int net = 0; net < 2; ++net) {
-      add_seg(w.wpart + (int64_t)net * out * in, grad + L.off_w[net][l], (int64_t)out * in,
+      add_seg(w.wpart[l] + (int64_t)net * out * in, grad + L.off_w[net][l], (int64_t)out * in,
               2 * (int64_t)out * in, splits, 0, 1.0f);
-      add_seg(w.bpart + (int64_t)net * splits * out, grad + L.off_b[net][l], out, out, splits, 0, 1.0f);
+      add_seg(w.bpart[l] + (int64_t)net * splits * out, grad + L.off_b[net][l], out, out, splits, 0, 1.0f);
     }
     if (l == nl - 1) {
-      // head partials + diagnostics ride along with the first reduction launch
+      // head partials + diagnostics ride along with the reduction launch
       const int NS = head_scalars(A);
       add_seg(w.head_w, grad + L.off_w[1][nl], (int64_t)A * HL, (int64_t)(A + 1) * HL, nbh, 0, 1.0f);
       add_seg(w.head_w + (int64_t)A * HL, grad + L.off_w[0][nl], HL, (int64_t)(A + 1) * HL, nbh, 0, 1.0f);
@@ -995,8 +1001,6 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
       add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, nbh, 1, hp->inv_global_batch);
     }
-    hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);
-    CATPPO_CHECK_LAUNCH(ctx);
     if (l > 0 && !rpt) {
       // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})   (the fused kernel already produced it)
       Params px{};
@@ -1014,8 +1018,13 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       CATPPO_CHECK_LAUNCH(ctx);
     }
   }
-  CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, side));
-  CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  // every split-K / head partial of the minibatch is folded into the flat gradient by one launch
+  hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);
+  CATPPO_CHECK_LAUNCH(ctx);
+  if (fork) {
+    CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, side));
+    CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+  }
 #undef CATPPO_HIP_OK
   return CATPPO_OK;
 }
