@@ -109,7 +109,7 @@ def load_library(path: Optional[str] = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("CATPPO_LIB") or LIB_PATH      # CATPPO_LIB: A/B another build of the library
     if not os.path.exists(path):
         raise RuntimeError(
             f"libcatppo.so not found at {path}: build it with "

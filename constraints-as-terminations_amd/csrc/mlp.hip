@@ -881,7 +881,13 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
   const int nbg = (int)cdiv64(M, kGatherRows);
   int nbh = (int)cdiv64(M, kHeadRowsPerBlock);
-  if (nbh > kHeadMaxBlocks) nbh = kHeadMaxBlocks;
+  // head_loss blocks = weight-gradient partials folded afterwards.  Its LDS tile decides residency: when only one
+  // block fits a CU (HL >= 256) a second round of blocks cannot overlap the first, so one block per CU walks
+  // several tiles and pays the set-up (head weights, advantage statistics, partial flush) once.
+  const size_t head_lds =
+      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
+  const int head_cap = 2 * head_lds > 160 * 1024 ? kHeadMaxBlocks / 2 : kHeadMaxBlocks;
+  if (nbh > head_cap) nbh = head_cap;
 
   // 1. gather the minibatch (ppo.py:300-302,314,331-337 index with mb_inds)
   hipLaunchKernelGGL(ppo_gather_kernel, dim3(nbg), dim3(256), 0, s, b_obs, b_actions, b_logprobs, b_advantages,
@@ -920,8 +926,6 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
     g.part_w = w.head_w, g.part_s = w.head_s;
     g.M = M, g.A = A, g.hp = *hp;
-    const size_t head_lds =
-        sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
     const int rc = dispatch_cpl(HL, [&](auto cpl) {
       constexpr int CPL = decltype(cpl)::value;
       auto kern = head_loss_kernel<CPL>;
