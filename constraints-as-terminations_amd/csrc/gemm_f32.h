@@ -63,8 +63,11 @@ __device__ __forceinline__ float elu_f(float z) {
   return z > 0.0f ? z : e;
 }
 
+// One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
+// (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
+__device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, const int nwg, const int bz,
+                                          float* __restrict__ smem) {
   constexpr int BK = BKT;                      // shadows gemm::BK inside the kernel
   constexpr int KC_STRIDE = BK + 4;            // floats, K-contig LDS row stride (80 B / 144 B: conflict-free b128)
   constexpr int KQ = BK / 4;                   // float4 per K-contig row of a slab
@@ -76,20 +79,19 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   constexpr int B_LD4 = BN * BK / 4 / 256;
   static_assert(A_LD4 >= 1 && B_LD4 >= 1, "tile too small for 256 threads");
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;                 // [2][A_TILE]
   float* Bs = smem + 2 * A_TILE;    // [2][B_TILE]
 
-  const int net = blockIdx.z % p.nets;
-  const int split = blockIdx.z / p.nets;
+  const int net = bz % p.nets;
+  const int split = bz / p.nets;
   const Operands op = p.op[net];   // by value: pointers live in SGPRs for the whole kernel
   // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, each XCD has a private L2.  Give
   // every XCD a contiguous range of the tile sequence (j fastest), so the tiles that share an A row
   // block hit the same L2 instead of fetching it once per XCD through the fabric.
   const int tiles_j = (p.J + BN - 1) / BN;
-  int wg = blockIdx.x;
+  int wg = wg_raw;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
   }
   const int i0 = (wg / tiles_j) * BM;
@@ -290,6 +292,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   }
   if (EPI == EPI_PARTIAL) {
     if (do_db && tid < BM && i0 + tid < p.I) op.dbias[(int64_t)split * p.I + i0 + tid] = dbsum;
+  }
+}
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+}
+
+// Two independent problems in ONE launch: the first n0 workgroups (in launch order) run problem 0, the rest
+// problem 1.  Used for a layer's weight gradient (few long split-K workgroups, one wave per SIMD when alone on a
+// CU) together with its data gradient (many short workgroups): the short ones fill the issue slots the long
+// ones leave idle, and one launch boundary disappears.
+template <int BM0, int BN0, bool A_KC0, bool B_KC0, int EPI0, int BM1, int BN1, bool A_KC1, bool B_KC1, int EPI1>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const Params p0, const Params p1, const int tiles0,
+                                                        const int n0, const int tiles1) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < n0) {
+    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0>(p0, b % tiles0, tiles0, b / tiles0, smem);
+  } else {
+    const int c = b - n0;
+    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1>(p1, c % tiles1, tiles1, c / tiles1, smem);
   }
 }
 

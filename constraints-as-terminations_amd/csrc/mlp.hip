@@ -151,6 +151,27 @@ void launch_gemm_auto(const Params& p, hipStream_t s) {
     launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s);
 }
 
+template <int BM, int BN>
+constexpr int tiles_of(const Params& p) { return ((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM); }
+
+// weight gradient (problem 0) + data gradient (problem 1, always 64x64 tiles) of one layer in one launch
+void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s) {
+  const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256;   // launch_gemm_auto's rule for EPI_PARTIAL
+  const int t1 = tiles_of<64, 64>(px), n1 = t1 * px.nets * px.splits;
+  constexpr size_t lds1 = gemm::smem_bytes<64, 64, true, false>();
+  if (big) {
+    const int t0 = tiles_of<128, 128>(pw), n0 = t0 * pw.nets * pw.splits;
+    constexpr size_t lds0 = gemm::smem_bytes<128, 128, false, false>();
+    gemm::gemm_pair_kernel<128, 128, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU>
+        <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
+  } else {
+    const int t0 = tiles_of<64, 64>(pw), n0 = t0 * pw.nets * pw.splits;
+    constexpr size_t lds0 = gemm::smem_bytes<64, 64, false, false>();
+    gemm::gemm_pair_kernel<64, 64, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU>
+        <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
+  }
+}
+
 // hidden-layer forward for `nets` networks starting at net index net0
 void forward_hidden(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, const float* params, const float* x,
                     int64_t M, const MlpWs& w, int net0, int nets, hipStream_t s) {
@@ -988,8 +1009,12 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       pw.op[net].C = w.wpart[l] + (int64_t)net * out * in;
       pw.op[net].dbias = w.bpart[l] + (int64_t)net * splits * out;   // [net][split][out]
     }
-    launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side);
-    CATPPO_CHECK_LAUNCH(ctx);
+    static const bool no_pair = getenv("CATPPO_NO_PAIR") != nullptr;
+    const bool pair = l > 0 && !rpt && !fork && !no_pair;
+    if (!pair) {
+      launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side);
+      CATPPO_CHECK_LAUNCH(ctx);
+    }
     for (int net = 0; net < 2; ++net) {
       add_seg(w.wpart[l] + (int64_t)net * out * in, grad + L.off_w[net][l], (int64_t)out * in,
               2 * (int64_t)out * in, splits, 0, 1.0f);
@@ -1018,7 +1043,10 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
         px.op[net].C = w.dZ[net][l - 1];
         px.op[net].aux = w.H[net][l - 1];
       }
-      launch_gemm_auto<true, false, gemm::EPI_MUL_DELU>(px, s);
+      if (pair)
+        launch_dw_dx_pair(pw, px, s);
+      else
+        launch_gemm_auto<true, false, gemm::EPI_MUL_DELU>(px, s);
       CATPPO_CHECK_LAUNCH(ctx);
     }
   }
