@@ -9,7 +9,7 @@ import csv
 import json
 import sys
 
-GROUP = ("gemm_f32_kernel", "head_loss_kernel", "seg_reduce_kernel", "ppo_gather_kernel")
+GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "seg_reduce_kernel", "ppo_gather_kernel")
 
 
 def per_launch(path):
@@ -23,8 +23,9 @@ def per_launch(path):
         if "<64, 64, true, true, 0" in r["kernel"]:
             s = s / calls * n_mb        # 64x64 forward launches also serve the rollout: one (K=Dp layer) per minibatch
         kib += s
-        detail[r["kernel"].split("(")[0][-60:]] = round(float(r["avg"]), 1)
-    gae = [float(r["avg"]) for r in rows if "gae_scan<1>" in r["kernel"]]
+        detail[r["kernel"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-70:]] = \
+            round(float(r["avg"]), 1)
+    gae = [float(r["avg"]) for r in rows if "gae_scan<1" in r["kernel"]]
     return kib / n_mb, n_mb, detail, (gae[0] if gae else None)
 
 

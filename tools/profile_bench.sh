@@ -1,0 +1,31 @@
+#!/bin/bash
+# rocprofv3 passes over bench.py on the GPU box; summaries land in gpurun_out/ (copy the ones to keep into profiles/).
+#   bash tools/profile_bench.sh [workload] [tag]
+# ROCm 7.2's rocprofv3 writes a rocpd SQLite database and can hang at process exit: every pass runs under
+# `timeout -s KILL` and is summarised from the database on the box (the databases are too big to bring back).
+# Counter passes are separate runs with nothing but --pmc (gpurun refuses --pmc mixed with trace domains).
+set -u
+WL=${1:-cfg2}
+TAG=${2:-r1}
+OUT=$PWD/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+CMD="python $PWD/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline"
+run_pass() {   # name, rocprof args...
+  local name=$1; shift
+  local dir=/tmp/prof_$name
+  rm -rf "$dir"
+  (cd /tmp && timeout -s KILL 240 rocprofv3 "$@" -d "$dir" -- $CMD > "$OUT/${TAG}_${name}.log" 2>&1)
+  find "$dir" -name '*.db' | head -1
+}
+DB=$(run_pass trace --kernel-trace)
+[ -n "$DB" ] && python tools/rocpd_stats.py "$DB" > "$OUT/${TAG}_bench_${WL}_kernel_stats.csv"
+for C in FETCH_SIZE WRITE_SIZE; do
+  DB=$(run_pass "pmc_$C" --pmc "$C")
+  [ -n "$DB" ] && python tools/rocpd_pmc.py "$DB" > "$OUT/${TAG}_pmc_${C}_${WL}.csv"
+done
+if [ -s "$OUT/${TAG}_pmc_FETCH_SIZE_${WL}.csv" ] && [ -s "$OUT/${TAG}_pmc_WRITE_SIZE_${WL}.csv" ]; then
+  python tools/pmc_group_traffic.py "$OUT/${TAG}_pmc_FETCH_SIZE_${WL}.csv" "$OUT/${TAG}_pmc_WRITE_SIZE_${WL}.csv" \
+    > "$OUT/${TAG}_pmc_traffic_${WL}.json"
+fi
+ls -la "$OUT" | tail -12
