@@ -63,6 +63,9 @@ _SIGNATURES = {
     "catppo_cat_reset": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "catppo_cat_terms": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _i32,
                                    _vp]),
+    "catppo_cat_terms_step": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
+                                        _i32, _vp, _vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                        _vp, _vp]),
     "catppo_env_pre_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                       _vp]),
     "catppo_rollout_store": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -232,6 +235,18 @@ class Native:
         cld = command.stride(0) if command is not None else 0
         self._ok(self.lib.catppo_cat_terms(self.h, arr, len(arr), int(n_envs), _p(forces), fstride, int(H), int(B),
                                            _p(command), cld, _p(cstr), cstr.shape[1], self._stream()))
+
+    def cat_terms_step(self, descs, forces, H, B, command, cstr, term_off_host, term_dp_host, min_p, tau, first_call,
+                       rm, cstr_prob, ep_viol, ep_prob, reward=None, reset_mask=None, dones=None, probs=None):
+        """cat_terms + cat_step in three launches (single-process path)"""
+        N, K = cstr.shape
+        fstride = forces.stride(0) if forces is not None else 0
+        cld = command.stride(0) if command is not None else 0
+        self._ok(self.lib.catppo_cat_terms_step(
+            self.h, descs, len(descs), N, _p(forces), fstride, int(H), int(B), _p(command), cld, _p(cstr), K,
+            C.cast(term_off_host, _vp), C.cast(term_dp_host, _vp), f32(min_p), f32(tau), f32(1.0 - tau),
+            int(bool(first_call)), _p(rm), _p(reward), _p(reset_mask), _p(cstr_prob), _p(dones), _p(ep_viol),
+            _p(ep_prob), _p(probs), self._stream()))
 
     def cat_reset(self, ep_viol, ep_prob, episode_length, mask, out, prev=None):
         n_terms, N = ep_viol.shape

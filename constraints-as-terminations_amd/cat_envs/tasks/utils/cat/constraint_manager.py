@@ -156,6 +156,8 @@ class ConstraintManager(ManagerBase):
         self._log_pos = 0
         self._bound = False
         self._fused = False
+        self._desc_cache = None
+        self.term_cache = True
         self._widths: List[int] = []
         self._term_off = None
         #: optional torch.distributed process group: envs are sharded over its ranks and the column
@@ -266,6 +268,29 @@ class ConstraintManager(ManagerBase):
         self.cat._bind_packed(self._term_names, widths, self.num_envs, nat.device)
         self._bound = True
 
+    def _describe_terms(self):
+        """descriptor table of the fused term kernel.  Built once and reused: the rows hold raw device pointers
+        into the simulator's persistent state buffers (IsaacLab's ``data.*`` tensors are allocated once and
+        updated in place) plus the term parameters, which only change through ``set_term_cfg`` (that drops
+        the cache).  ``self.term_cache = False`` re-describes every step."""
+        cache = self._desc_cache if self.term_cache else None
+        if cache is not None:
+            return cache
+        env = self._env
+        rows, forces, command, H, B, keep = [], None, None, 1, 1, []
+        for cfg in self._term_cfgs:
+            d = cfg.func.describe(env, **cfg.params)
+            rows.append(d.c)
+            keep.append(d)                          # keeps the tensors behind the pointers alive
+            if d.forces is not None:
+                forces, H, B = d.forces, d.forces.shape[1], d.forces.shape[2]
+            if d.command is not None:
+                command = d.command
+        arr = (native.TermDesc * len(rows))(*rows)
+        self._desc_keep = keep
+        self._desc_cache = (arr, forces, H, B, command)
+        return self._desc_cache
+
     def compute(self, reward: torch.Tensor | None = None, reset_mask: torch.Tensor | None = None,
                 dones: torch.Tensor | None = None) -> torch.Tensor:
         """Termination probability per env.  The optional arguments fuse the three lines of
@@ -278,15 +303,17 @@ class ConstraintManager(ManagerBase):
         if not self._bound:
             self._bind(nat)
         env, cat = self._env, self.cat
+        group = self.dist_group
+        sharded = group is not None and parallel.active(group)
+        dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
+        args = dict(reward=reward, reset_mask=reset_mask, dones=dones, probs=cat._p_probs)
         if self._fused:
-            descs, forces, command, H, B = [], None, None, 1, 1
-            for cfg in self._term_cfgs:
-                d = cfg.func.describe(env, **cfg.params)
-                descs.append(d.c)
-                if d.forces is not None:
-                    forces, H, B = d.forces, d.forces.shape[1], d.forces.shape[2]
-                if d.command is not None:
-                    command = d.command
+            descs, forces, H, B, command = self._describe_terms()
+            if not sharded:
+                nat.cat_terms_step(descs, forces, H, B, command, cat._p_cstr, self._term_off, dp, cat.min_p, cat.tau,
+                                   cat._p_first, cat._p_rm, self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)
+                cat._p_first = False
+                return self._cstr_prob_buf
             nat.cat_terms(descs, self.num_envs, forces, H, B, command, cat._p_cstr)
         else:
             off = 0
@@ -294,10 +321,7 @@ class ConstraintManager(ManagerBase):
                 out = cfg.func(env, **cfg.params)
                 cat._p_cstr[:, off:off + w].copy_(out.reshape(self.num_envs, w))   # bool -> float in the copy
                 off += w
-        dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
-        args = dict(reward=reward, reset_mask=reset_mask, dones=dones, probs=cat._p_probs)
-        group = self.dist_group
-        if group is not None and parallel.active(group):
+        if sharded:
             if not hasattr(self, "_colmax"):
                 self._colmax = torch.zeros_like(cat._p_rm)
             nat.cat_colmax(cat._p_cstr, self._colmax)
@@ -319,7 +343,13 @@ class ConstraintManager(ManagerBase):
     def set_term_cfg(self, term_name: str, cfg: ConstraintTermCfg):
         if term_name not in self._term_names:
             raise ValueError(f"Constraint term '{term_name}' not found.")
-        self._term_cfgs[self._term_names.index(term_name)] = cfg
+        i = self._term_names.index(term_name)
+        old = self._term_cfgs[i]
+        self._term_cfgs[i] = cfg
+        # the curriculum rewrites max_p through here at every reset; only a different function / parameter set
+        # changes the descriptor table of the fused term kernel
+        if cfg.func is not old.func or cfg.params is not old.params and cfg.params != old.params:
+            self._desc_cache = None
 
     def get_term_cfg(self, term_name: str) -> ConstraintTermCfg:
         if term_name not in self._term_names:

@@ -308,6 +308,30 @@ extern "C" int catppo_cat_step(catppo_ctx* ctx, const float* cstr, int64_t N, in
                        dones, ep_viol, ep_prob, probs, s);
 }
 
+extern "C" int catppo_cat_terms_step(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
+                                     const float* forces, int64_t forces_env_stride, int H, int B,
+                                     const float* command, int command_ld, float* cstr, int K,
+                                     const int32_t* term_off, const float* term_dp, float min_p, float tau,
+                                     float one_minus_tau, int first_call, float* rm, float* reward,
+                                     const uint8_t* reset_mask, float* cstr_prob, float* dones, float* ep_viol,
+                                     float* ep_prob, float* probs, void* stream) {
+  if (int rc = check_common(ctx, cstr, N, K, n_terms)) return rc;
+  CATPPO_CHECK_ARG(ctx, desc && term_off && term_dp && rm && cstr_prob && ep_viol && ep_prob);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WsCarver ws(ctx);
+  float* partial = ws.take<float>((uint64_t)256 * K);
+  CATPPO_NEED_WS(ctx, partial);
+  int nblk = 0;
+  if (int rc = catppo_internal_launch_terms(ctx, desc, n_terms, N, forces, forces_env_stride, H, B, command,
+                                            command_ld, cstr, K, partial, &nblk, s))
+    return rc;
+  hipLaunchKernelGGL(cat_reduce_ema, dim3(1), dim3(kThreads), 0, s, partial, nblk, K, (float*)nullptr, rm, 1,
+                     first_call, tau, one_minus_tau);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return launch_finish(ctx, cstr, N, K, term_off, n_terms, term_dp, min_p, rm, reward, reset_mask, cstr_prob,
+                       dones, ep_viol, ep_prob, probs, s);
+}
+
 extern "C" int catppo_cat_reset(catppo_ctx* ctx, float* ep_viol, float* ep_prob, const int64_t* episode_length,
                                 const uint8_t* mask, int n_terms, int64_t N, const float* prev, float* out,
                                 void* stream) {

@@ -70,5 +70,12 @@ struct WsCarver {
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// cat_terms.hip: evaluate the term table into cstr[N,K]; with `colmax_partial` ([<=256][K], may be null) every
+// workgroup also writes the column maxima of the rows it produced, *nblk_out = number of partial rows
+int catppo_internal_launch_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
+                                 const float* forces, int64_t forces_env_stride, int H, int B, const float* command,
+                                 int command_ld, float* cstr, int K, float* colmax_partial, int* nblk_out,
+                                 hipStream_t stream);
+
 // NaN-propagating max (torch.max semantics): once NaN, stays NaN
 __device__ __forceinline__ float nanmax(float m, float x) { return (x > m || x != x) ? x : m; }

@@ -137,6 +137,17 @@ int catppo_cat_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms,
                      const float* forces, int64_t forces_env_stride, int H, int B,
                      const float* command, int command_ld, float* cstr, int K, void* stream);
 
+/* catppo_cat_terms + catppo_cat_step in three launches: the term kernel also emits the per-workgroup column
+ * maxima, so the CaT step does not re-read cstr for them.  Same arguments as the two calls (n_terms is both
+ * the descriptor count and the term count of term_off / term_dp).  Single-process runs only: env-sharded runs
+ * need the all-reduce point between catppo_cat_colmax and catppo_cat_apply. */
+int catppo_cat_terms_step(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
+                          const float* forces, int64_t forces_env_stride, int H, int B, const float* command,
+                          int command_ld, float* cstr, int K, const int32_t* term_off, const float* term_dp,
+                          float min_p, float tau, float one_minus_tau, int first_call, float* rm, float* reward,
+                          const uint8_t* reset_mask, float* cstr_prob, float* dones, float* ep_viol,
+                          float* ep_prob, float* probs, void* stream);
+
 /* ---- env-step bookkeeping, fused ------------------------------------------------------------
  * catppo_env_pre_step: process_action (prev <- action, action <- action_in, [N,A]); episode_length += 1;
  *   time_outs = episode_length >= max_episode_length; terminated = hard_reset > 0.5; reset = either;
