@@ -25,7 +25,7 @@ TERM_ACTION_RATE, TERM_FORCE_LIMIT, TERM_LIMIT_MINUS, TERM_ABS_LIMIT_GATE_CMDNOR
 
 class MlpShape(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("act_dim", C.c_int32), ("n_hidden", C.c_int32),
-                ("hidden", C.c_int32 * MAX_HIDDEN)]
+                ("hidden", C.c_int32 * MAX_HIDDEN), ("mfma_bf16", C.c_int32)]
 
 
 class MlpLayout(C.Structure):
@@ -130,9 +130,10 @@ def f32(x: float) -> float:
     return C.c_float(x).value
 
 
-def shape_of(obs_dim: int, act_dim: int, hidden) -> MlpShape:
+def shape_of(obs_dim: int, act_dim: int, hidden, mfma_bf16: bool = False) -> MlpShape:
     s = MlpShape()
     s.obs_dim, s.act_dim, s.n_hidden = int(obs_dim), int(act_dim), len(hidden)
+    s.mfma_bf16 = int(bool(mfma_bf16))
     for i, h in enumerate(hidden):
         s.hidden[i] = int(h)
     return s

@@ -103,8 +103,11 @@ class Agent(nn.Module):
     kernels read and update that buffer directly.
     """
 
-    def __init__(self, envs, hidden=DEFAULT_HIDDEN, device=None):
+    def __init__(self, envs, hidden=DEFAULT_HIDDEN, device=None, mlp_precision: str = "fp32"):
         super().__init__()
+        if mlp_precision not in ("fp32", "bf16"):
+            raise ValueError(f"mlp_precision must be 'fp32' or 'bf16', got {mlp_precision!r}")
+        self.mlp_precision = mlp_precision
         obs_shape = envs.unwrapped.single_observation_space["policy"].shape
         act_shape = envs.unwrapped.single_action_space.shape
         self.obs_dim, self.act_dim = int(np.array(obs_shape).prod()), int(np.prod(act_shape))
@@ -112,7 +115,7 @@ class Agent(nn.Module):
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         device = torch.device(device)
-        self.shape = native.shape_of(self.obs_dim, self.act_dim, self.hidden)
+        self.shape = native.shape_of(self.obs_dim, self.act_dim, self.hidden, mfma_bf16=mlp_precision == "bf16")
         self.layout = native.layout_of(self.shape)
 
         def mlp(out_dim, out_std):
@@ -255,7 +258,8 @@ class PPOTrainer:
         self.mb = int(c.minibatch_size)
         self.world, self.rank = parallel.world_size(), parallel.rank()
         hidden = tuple(getattr(c, "hidden", None) or DEFAULT_HIDDEN)
-        self.agent = agent if agent is not None else Agent(envs, hidden=hidden).to(self.device)
+        self.agent = agent if agent is not None else Agent(
+            envs, hidden=hidden, mlp_precision=str(getattr(c, "mlp_precision", "fp32"))).to(self.device)
         a = self.agent
         self.D, self.A, self.Dp = a.obs_dim, a.act_dim, a.layout.obs_pad
         if parallel.active():

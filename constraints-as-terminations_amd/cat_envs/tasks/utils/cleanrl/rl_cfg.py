@@ -38,3 +38,6 @@ class CleanRlPpoActorCriticCfg:
     #: env-sharded runs: all-reduce the cross-env statistics (CaT column max, normaliser moments,
     #: minibatch advantage mean/std) so that N ranks reproduce one process on the union of shards
     dist_exact: bool = True
+    #: "fp32" = the reference's numerics (fp32-input MFMA).  "bf16" = hidden-layer GEMM operands rounded to bf16,
+    #: fp32 accumulation, fp32 master weights / activations / optimiser (BASELINE config 5); not a parity mode.
+    mlp_precision: str = "fp32"

@@ -27,6 +27,7 @@
 namespace gemm {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int BK = 16;             // default contraction slab; kernels take it as the BKT template parameter
 
@@ -65,7 +66,7 @@ __device__ __forceinline__ float elu_f(float z) {
 
 // One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
 // (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, bool BF16 = false>
 __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, const int nwg, const int bz,
                                           float* __restrict__ smem) {
   constexpr int BK = BKT;                      // shadows gemm::BK inside the kernel
@@ -214,9 +215,8 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
       }
     }
 
-#pragma unroll
-    for (int blk = 0; blk < BK / 8; ++blk) {
-      float af[TM][4], bf[TN][4];
+    // fragment of 4 consecutive k (k = 8*blk + 4*h + 0..3) of operand rows `row` for every 32-row tile
+    auto frag_a = [&](int blk, float (&af)[TM][4]) {
 #pragma unroll
       for (int t = 0; t < TM; ++t) {
         const int row = wm * WM + t * 32 + l31;
@@ -228,6 +228,8 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
           for (int q = 0; q < 4; ++q) af[t][q] = a[(8 * blk + 4 * h + q) * BM + row];
         }
       }
+    };
+    auto frag_b = [&](int blk, float (&bf)[TN][4]) {
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
         const int col = wn * WN + t * 32 + l31;
@@ -239,13 +241,48 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
           for (int q = 0; q < 4; ++q) bf[t][q] = b[(8 * blk + 4 * h + q) * BN + col];
         }
       }
+    };
+    if constexpr (!BF16) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int blk = 0; blk < BK / 8; ++blk) {
+        float af[TM][4], bf[TN][4];
+        frag_a(blk, af);
+        frag_b(blk, bf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][q], bf[tn][q], acc[tm][tn], 0, 0, 0);
+      }
+    } else {
+      // bf16 operands, fp32 accumulation: the same fp32 LDS images, rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on
+      // the way into ONE v_mfma_f32_32x32x16_bf16 per 16 k.  Slot (h, i) of the instruction carries
+      // k = 8*(i/4) + 4*h + i%4 for A and B alike, so the contraction is complete and each product exact.
+      static_assert(!BF16 || BK % 16 == 0, "bf16 path consumes 16 k per MFMA");
+#pragma unroll
+      for (int kb = 0; kb < BK / 16; ++kb) {
+        float a0[TM][4], a1[TM][4], b0[TN][4], b1[TN][4];
+        frag_a(2 * kb, a0);
+        frag_a(2 * kb + 1, a1);
+        frag_b(2 * kb, b0);
+        frag_b(2 * kb + 1, b1);
+        bf16x8 pa[TM], pb[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pa[t][q] = (__bf16)a0[t][q], pa[t][4 + q] = (__bf16)a1[t][q];
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pb[t][q] = (__bf16)b0[t][q], pb[t][4 + q] = (__bf16)b1[t][q];
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[tm][q], bf[tn][q], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[tm], pb[tn], acc[tm][tn], 0, 0, 0);
+      }
     }
 
     if (s + 1 < n_slabs) lstore(cur ^ 1);
@@ -295,26 +332,27 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT, BF16>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
 }
 
 // Two independent problems in ONE launch: the first n0 workgroups (in launch order) run problem 0, the rest
 // problem 1.  Used for a layer's weight gradient (few long split-K workgroups, one wave per SIMD when alone on a
 // CU) together with its data gradient (many short workgroups): the short ones fill the issue slots the long
 // ones leave idle, and one launch boundary disappears.
-template <int BM0, int BN0, bool A_KC0, bool B_KC0, int EPI0, int BM1, int BN1, bool A_KC1, bool B_KC1, int EPI1>
+template <int BM0, int BN0, bool A_KC0, bool B_KC0, int EPI0, int BM1, int BN1, bool A_KC1, bool B_KC1, int EPI1,
+          bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const Params p0, const Params p1, const int tiles0,
                                                         const int n0, const int tiles1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < n0) {
-    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0>(p0, b % tiles0, tiles0, b / tiles0, smem);
+    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0, BK, BF16>(p0, b % tiles0, tiles0, b / tiles0, smem);
   } else {
     const int c = b - n0;
-    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1>(p1, c % tiles1, tiles1, c / tiles1, smem);
+    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1, BK, BF16>(p1, c % tiles1, tiles1, c / tiles1, smem);
   }
 }
 

@@ -129,46 +129,57 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
 
 // ------------------------------------------------------------------------------- GEMM launch
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-void launch_gemm(const Params& p, hipStream_t s) {
+void launch_gemm(const Params& p, hipStream_t s, bool bf16) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);   // 1-D tile index, see kernel
   constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
-  gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI><<<grid, dim3(256), lds, s>>>(p);
+  if (bf16)
+    gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, true><<<grid, dim3(256), lds, s>>>(p);
+  else
+    gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI><<<grid, dim3(256), lds, s>>>(p);
 }
 
 // Tile choice from tools/gemm_probe on MI355X (M=16384, both nets per launch): 128x128 pays only when
 // the contraction is long enough to amortise its heavier epilogue and there are >= 1.5 workgroups per
 // CU; the data-gradient form (aux read + store epilogue) is always better with 64x64 tiles.
 template <bool A_KC, bool B_KC, int EPI>
-void launch_gemm_auto(const Params& p, hipStream_t s) {
+void launch_gemm_auto(const Params& p, hipStream_t s, bool bf16) {
   const int64_t big = (int64_t)((p.I + 127) / 128) * ((p.J + 127) / 128) * p.nets * p.splits;
   const int kc = EPI == gemm::EPI_PARTIAL ? p.kc_per_split : p.Kc;
   // weight gradients pick their split count to fill the chip, so only the shape matters there
   const bool use_big = EPI != gemm::EPI_MUL_DELU && p.I >= 128 && p.J >= 128 && kc >= 256 &&
                        (EPI == gemm::EPI_PARTIAL || big >= 384);
   if (use_big)
-    launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s);
+    launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, bf16);
   else
-    launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s);
+    launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, bf16);
 }
 
 template <int BM, int BN>
 constexpr int tiles_of(const Params& p) { return ((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM); }
 
 // weight gradient (problem 0) + data gradient (problem 1, always 64x64 tiles) of one layer in one launch
-void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s) {
+void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, bool bf16) {
   const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256;   // launch_gemm_auto's rule for EPI_PARTIAL
   const int t1 = tiles_of<64, 64>(px), n1 = t1 * px.nets * px.splits;
   constexpr size_t lds1 = gemm::smem_bytes<64, 64, true, false>();
   if (big) {
     const int t0 = tiles_of<128, 128>(pw), n0 = t0 * pw.nets * pw.splits;
     constexpr size_t lds0 = gemm::smem_bytes<128, 128, false, false>();
-    gemm::gemm_pair_kernel<128, 128, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU>
-        <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
+    if (bf16)
+      gemm::gemm_pair_kernel<128, 128, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU, true>
+          <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
+    else
+      gemm::gemm_pair_kernel<128, 128, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU>
+          <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
   } else {
     const int t0 = tiles_of<64, 64>(pw), n0 = t0 * pw.nets * pw.splits;
     constexpr size_t lds0 = gemm::smem_bytes<64, 64, false, false>();
-    gemm::gemm_pair_kernel<64, 64, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU>
-        <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
+    if (bf16)
+      gemm::gemm_pair_kernel<64, 64, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU, true>
+          <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
+    else
+      gemm::gemm_pair_kernel<64, 64, false, false, gemm::EPI_PARTIAL, 64, 64, true, false, gemm::EPI_MUL_DELU>
+          <<<dim3(n0 + n1), dim3(256), lds0 > lds1 ? lds0 : lds1, s>>>(pw, px, t0, n0, t1);
   }
 }
 
@@ -192,7 +203,7 @@ void forward_hidden(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, cons
       p.op[n].bias = params + L.off_b[net][l];
       p.op[n].C = w.H[net][l];
     }
-    launch_gemm_auto<true, true, gemm::EPI_BIAS_ELU>(p, s);
+    launch_gemm_auto<true, true, gemm::EPI_BIAS_ELU>(p, s, sh->mfma_bf16 != 0);
   }
 }
 
@@ -758,7 +769,7 @@ int fused_variant(const catppo_mlp_shape* sh) {
     const char* e = getenv("CATPPO_FUSED");
     return e ? atoi(e) : 0;
   }();
-  if (forced <= 0) return 0;
+  if (forced <= 0 || sh->mfma_bf16) return 0;   // the row-tile kernel has no bf16-operand variant
   int maxw = 0;
   for (int l = 0; l < sh->n_hidden; ++l) maxw = sh->hidden[l] > maxw ? sh->hidden[l] : maxw;
   if (maxw > 512) return 0;
@@ -972,6 +983,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   // layer's dZ exists, and everything is joined before returning to the caller's stream order.
   // The split-K partial buffers are reused layer after layer; the side stream serialises them.
   const bool fork = ctx->use_side;
+  const bool bf16 = shape->mfma_bf16 != 0;
   hipStream_t side = fork ? ctx->side : s;
 #define CATPPO_HIP_OK(call)                                                                          \
   do {                                                                                               \
@@ -1012,7 +1024,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
     static const bool no_pair = getenv("CATPPO_NO_PAIR") != nullptr;
     const bool pair = l > 0 && !rpt && !fork && !no_pair;
     if (!pair) {
-      launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side);
+      launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
       CATPPO_CHECK_LAUNCH(ctx);
     }
     for (int net = 0; net < 2; ++net) {
@@ -1044,9 +1056,9 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
         px.op[net].aux = w.H[net][l - 1];
       }
       if (pair)
-        launch_dw_dx_pair(pw, px, s);
+        launch_dw_dx_pair(pw, px, s, bf16);
       else
-        launch_gemm_auto<true, false, gemm::EPI_MUL_DELU>(px, s);
+        launch_gemm_auto<true, false, gemm::EPI_MUL_DELU>(px, s, bf16);
       CATPPO_CHECK_LAUNCH(ctx);
     }
   }

@@ -238,6 +238,10 @@ typedef struct catppo_mlp_shape {
   int32_t act_dim;                  /* A  (<= 15) */
   int32_t n_hidden;                 /* L  (1..CATPPO_MAX_HIDDEN) */
   int32_t hidden[CATPPO_MAX_HIDDEN]; /* widths, each a multiple of 64 */
+  int32_t mfma_bf16;                /* 0: fp32-input MFMA (reference numerics, default).  1: the hidden-layer GEMMs
+                                       (forward, data gradient, weight gradient) round their operands to bf16
+                                       (RNE) and use v_mfma_f32_32x32x16_bf16 with fp32 accumulation; parameters,
+                                       activations, gradients and the optimiser stay fp32 (BASELINE config 5). */
 } catppo_mlp_shape;
 
 typedef struct catppo_mlp_layout {

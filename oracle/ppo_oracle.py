@@ -63,12 +63,33 @@ class RMSOracle:
 
 
 # ------------------------------------------------------------------ actor / critic
-def mlp_forward(x: torch.Tensor, layers) -> torch.Tensor:
+def _q(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _BF16OperandLinear(torch.autograd.Function):
+    """Restatement of the build's bf16 mode (catppo_mlp_shape.mfma_bf16, BASELINE config 5 - NOT a reference
+    code path): every hidden-layer GEMM rounds both operands to bf16 (RNE) and accumulates in fp32, in the
+    forward (x.w^T), the data gradient (gy.w) and the weight gradient (gy^T.x); bias and its gradient fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return _q(x) @ _q(w).t() + b
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        return _q(gy) @ _q(w), _q(gy).t() @ _q(x), gy.sum(0)
+
+
+def mlp_forward(x: torch.Tensor, layers, bf16_hidden: bool = False) -> torch.Tensor:
     """layers = [(W(out,in), b), ...]; ELU(alpha=1) between, none after the last."""
     h = x
     for i, (w, b) in enumerate(layers):
-        h = F.linear(h, w, b)
-        if i + 1 < len(layers):
+        last = i + 1 == len(layers)
+        h = _BF16OperandLinear.apply(h, w, b) if (bf16_hidden and not last) else F.linear(h, w, b)
+        if not last:
             h = F.elu(h)
     return h
 
@@ -86,7 +107,8 @@ def gaussian_logp_entropy(mean, logstd, action):
 class AgentOracle:
     """Parameters as plain tensors under the reference's 23 state_dict keys."""
 
-    def __init__(self, obs_dim: int, act_dim: int, hidden=(512, 256, 128), seed: int = 0):
+    def __init__(self, obs_dim: int, act_dim: int, hidden=(512, 256, 128), seed: int = 0, bf16_hidden: bool = False):
+        self.bf16_hidden = bool(bf16_hidden)
         g = torch.Generator().manual_seed(seed)
         dims = [obs_dim, *hidden]
         self.p: dict[str, torch.Tensor] = {"actor_logstd": torch.zeros(1, act_dim)}
@@ -132,10 +154,10 @@ class AgentOracle:
         return sd
 
     def get_value(self, x):
-        return mlp_forward(x, self.layers("critic"))
+        return mlp_forward(x, self.layers("critic"), self.bf16_hidden)
 
     def get_action_and_value(self, x, action=None, eps=None, deterministic=False):
-        mean = mlp_forward(x, self.layers("actor_mean"))
+        mean = mlp_forward(x, self.layers("actor_mean"), self.bf16_hidden)
         if action is None:
             if deterministic:
                 action = mean

@@ -61,7 +61,7 @@ def main(argv=None):
     print(f"[INFO] Loading model: {resume_path}")
 
     env = make(args_cli.task, cfg=env_cfg)
-    actor = Agent(env, hidden=tuple(agent_cfg.hidden))
+    actor = Agent(env, hidden=tuple(agent_cfg.hidden), mlp_precision=str(getattr(agent_cfg, "mlp_precision", "fp32")))
     actor.load_state_dict(torch.load(resume_path, map_location=actor.flat.device))
     actor.eval()
 

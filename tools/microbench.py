@@ -78,9 +78,10 @@ def main():
         out.append(dict(kernel="rms update+normalize(4 launches)", N=N, D=D, us=us, GBps=N * D * 12 / us / 1e3))
 
     # ---- MLP
-    for D, hidden in [(45, (512, 256, 128)), (48, (256, 256, 256))]:
+    for D, hidden, bf16 in [(45, (512, 256, 128), False), (48, (256, 256, 256), False), (48, (256, 256, 256), True)]:
         A = 12
-        shape = native.shape_of(D, A, hidden)
+        shape = native.shape_of(D, A, hidden, mfma_bf16=bf16)
+        tag = "[bf16 operands]" if bf16 else ""
         lay = native.layout_of(shape)
         dims = [lay.obs_pad, *hidden]
         macs_true = sum(i * o for i, o in zip([D, *hidden[:-1]], hidden)) * 2 + hidden[-1] * (A + 1)
@@ -92,7 +93,7 @@ def main():
             nat.mlp_reserve(shape, 16384)
             us = timeit(lambda: nat.policy_act(shape, params, x, N, eps, act, lp, val), a.reps)
             fl = 2 * macs_true * N
-            out.append(dict(kernel="policy_act", arch=list(hidden), D=D, N=N, us=us, TFLOPs=fl / us / 1e6,
+            out.append(dict(kernel="policy_act" + tag, arch=list(hidden), D=D, N=N, us=us, TFLOPs=fl / us / 1e6,
                             frac_157TF=fl / us / 1e6 / 157.3))
         B, M = 98304, 16384
         obs, acts = torch.randn(B, lay.obs_pad, device=dev), torch.randn(B, A, device=dev)
@@ -105,7 +106,7 @@ def main():
         us = timeit(lambda: nat.ppo_minibatch_grad(shape, hp, params, obs, acts, logp, adv, ret, val, inds, vm, vv,
                                                    None, grad, diag), max(a.reps // 2, 5))
         fl = 6 * macs_true * M
-        out.append(dict(kernel="ppo_minibatch_grad", arch=list(hidden), D=D, M=M, us=us, TFLOPs=fl / us / 1e6,
+        out.append(dict(kernel="ppo_minibatch_grad" + tag, arch=list(hidden), D=D, M=M, us=us, TFLOPs=fl / us / 1e6,
                         frac_157TF=fl / us / 1e6 / 157.3))
         m1, m2 = torch.zeros(lay.n_flat, device=dev), torch.zeros(lay.n_flat, device=dev)
         us = timeit(lambda: nat.clip_adam(params, grad, m1, m2, lay.n_flat, 1.0, 3e-4, 0.9, 0.999, 1e-5, 3), a.reps)
