@@ -74,6 +74,8 @@ _SIGNATURES = {
     "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
     "catppo_gae_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
                                 _vp]),
+    "catppo_gae_f16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
+                                 _vp]),
     "catppo_adv_normalize": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "catppo_value_bootstrap": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i64, _vp]),
     "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
@@ -291,6 +293,18 @@ class Native:
                                      _p(advantages), _p(returns), T, N, self._stream()))
 
     GAE_CLEANRL, GAE_RL_GAMES, GAE_SKRL = 0, 1, 2
+
+    def gae_f16(self, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gae_lambda,
+                advantages, returns, kind=0):
+        """fp16 rollout planes; ``gae_lambda`` is lambda (the product with gamma is formed here, except for skrl)"""
+        T, N = rewards.shape
+        for n, t in (("rewards", rewards), ("values", values), ("dones", dones), ("next_value", next_value),
+                     ("advantages", advantages), ("returns", returns)):
+            _chk(t, torch.float16, n)
+        gl = gae_lambda if kind == self.GAE_SKRL else gamma * gae_lambda
+        self._ok(self.lib.catppo_gae_f16(self.h, int(kind), _p(rewards), _p(values), _p(dones), _p(true_dones),
+                                         _p(next_value), _p(next_done), _p(next_true_done), f32(gamma), f32(gl),
+                                         _p(advantages), _p(returns), T, N, self._stream()))
 
     def gae_rl_games(self, fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma, tau, advantages, returns):
         """rl_games discount_values with float dones ((T,N) planes, time major)"""

@@ -14,26 +14,30 @@
 
 namespace {
 
-// every element of the (T,N) planes is touched exactly once: stream them past the caches (nt)
-template <int VEC>
-__device__ __forceinline__ void load(const float* p, float (&v)[VEC]) {
+// every element of the (T,N) planes is touched exactly once: stream them past the caches (nt).
+// ST = storage type of the planes: float, or _Float16 (BASELINE config 5 "fp16 rollout buffer": the recurrence
+// still runs in fp32 on the widened values, results are rounded to fp16 (RNE) on the way out).
+template <int VEC, typename ST>
+__device__ __forceinline__ void load(const ST* p, float (&v)[VEC]) {
+  using vec_t = __attribute__((ext_vector_type(VEC))) ST;
   if constexpr (VEC == 1) {
-    v[0] = __builtin_nontemporal_load(p);
+    v[0] = (float)__builtin_nontemporal_load(p);
   } else {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    const f4 q = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
-    v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+    const vec_t q = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(p));
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) v[k] = (float)q[k];
   }
 }
-template <int VEC>
-__device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
+template <int VEC, typename ST>
+__device__ __forceinline__ void store(ST* p, const float (&v)[VEC]) {
+  using vec_t = __attribute__((ext_vector_type(VEC))) ST;
   if constexpr (VEC == 1) {
-    __builtin_nontemporal_store(v[0], p);
+    __builtin_nontemporal_store((ST)v[0], p);
   } else {
-    using f4 = __attribute__((ext_vector_type(4))) float;
-    f4 q;
-    q.x = v[0], q.y = v[1], q.z = v[2], q.w = v[3];
-    __builtin_nontemporal_store(q, reinterpret_cast<f4*>(p));
+    vec_t q;
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) q[k] = (ST)v[k];
+    __builtin_nontemporal_store(q, reinterpret_cast<vec_t*>(p));
   }
 }
 
@@ -42,20 +46,20 @@ __device__ __forceinline__ void store(float* p, const float (&v)[VEC]) {
 //   1 rl_games  (rl_games/cat_common.py:96-103 -> A2CBase.discount_values with float fdones): the CleanRL
 //               recurrence without the time-out channel (tn == 1 exactly, one plane less to read)
 //   2 skrl      (skrl/ppo.py:397-442)        d = done_t:  A_t = (r_t - v_t) + (g*nd_t) * (v_{t+1} + l*A_{t+1})
-template <int VEC, int KIND>
-__global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, const float* __restrict__ val,
-                                                const float* __restrict__ done, const float* __restrict__ tdone,
-                                                const float* __restrict__ next_val,
-                                                const float* __restrict__ next_done,
-                                                const float* __restrict__ next_tdone, float gamma, float gl,
-                                                float* __restrict__ adv, float* __restrict__ ret, int T,
+template <int VEC, int KIND, typename ST = float>
+__global__ __launch_bounds__(256) void gae_scan(const ST* __restrict__ rew, const ST* __restrict__ val,
+                                                const ST* __restrict__ done, const ST* __restrict__ tdone,
+                                                const ST* __restrict__ next_val,
+                                                const ST* __restrict__ next_done,
+                                                const ST* __restrict__ next_tdone, float gamma, float gl,
+                                                ST* __restrict__ adv, ST* __restrict__ ret, int T,
                                                 int64_t N) {
   const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (env >= N) return;
   float vnext[VEC], dn[VEC], tdn[VEC], last[VEC];
-  load<VEC>(next_val + env, vnext);
-  if constexpr (KIND != 2) load<VEC>(next_done + env, dn);
-  if constexpr (KIND == 0) load<VEC>(next_tdone + env, tdn);
+  load<VEC, ST>(next_val + env, vnext);
+  if constexpr (KIND != 2) load<VEC, ST>(next_done + env, dn);
+  if constexpr (KIND == 0) load<VEC, ST>(next_tdone + env, tdn);
 #pragma unroll
   for (int k = 0; k < VEC; ++k) last[k] = 0.0f;
 
@@ -63,10 +67,10 @@ __global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, c
   for (int t = T - 1; t >= 0; --t) {
     const int64_t off = (int64_t)t * N + env;
     float r[VEC], v[VEC], d[VEC], td[VEC], a[VEC], q[VEC];
-    load<VEC>(rew + off, r);
-    load<VEC>(val + off, v);
-    load<VEC>(done + off, d);     // KIND 0/1: consumed by step t-1;  KIND 2: by this step
-    if constexpr (KIND == 0) load<VEC>(tdone + off, td);
+    load<VEC, ST>(rew + off, r);
+    load<VEC, ST>(val + off, v);
+    load<VEC, ST>(done + off, d);     // KIND 0/1: consumed by step t-1;  KIND 2: by this step
+    if constexpr (KIND == 0) load<VEC, ST>(tdone + off, td);
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
       if constexpr (KIND == 2) {
@@ -98,33 +102,32 @@ __global__ __launch_bounds__(256) void gae_scan(const float* __restrict__ rew, c
       q[k] = last[k] + v[k];        // returns = advantages + values
       vnext[k] = v[k];
     }
-    store<VEC>(adv + off, a);
-    store<VEC>(ret + off, q);
+    store<VEC, ST>(adv + off, a);
+    store<VEC, ST>(ret + off, q);
   }
 }
 
-template <int KIND>
-void launch_gae(bool wide, const float* rewards, const float* values, const float* dones, const float* true_dones,
-                const float* next_value, const float* next_done, const float* next_true_done, float gamma, float gl,
-                float* advantages, float* returns, int T, int64_t N, hipStream_t s) {
+template <int KIND, typename ST>
+void launch_gae(bool wide, const ST* rewards, const ST* values, const ST* dones, const ST* true_dones,
+                const ST* next_value, const ST* next_done, const ST* next_true_done, float gamma, float gl,
+                ST* advantages, ST* returns, int T, int64_t N, hipStream_t s) {
+  constexpr int WV = 16 / (int)sizeof(ST);     // 16-B lanes: 4 fp32 / 8 fp16 envs
   if (wide) {
     const int block = 256;
-    gae_scan<4, KIND><<<dim3((unsigned)cdiv64(N / 4, block)), dim3(block), 0, s>>>(
+    gae_scan<WV, KIND, ST><<<dim3((unsigned)cdiv64(N / WV, block)), dim3(block), 0, s>>>(
         rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gl, advantages, returns, T, N);
   } else {
     // small N: one wave per block so that 4096 envs already spread over 64 CUs
     const int block = N >= 65536 ? 256 : 64;
-    gae_scan<1, KIND><<<dim3((unsigned)cdiv64(N, block)), dim3(block), 0, s>>>(
+    gae_scan<1, KIND, ST><<<dim3((unsigned)cdiv64(N, block)), dim3(block), 0, s>>>(
         rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gl, advantages, returns, T, N);
   }
 }
 
-}  // namespace
-
-extern "C" int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values,
-                             const float* dones, const float* true_dones, const float* next_value,
-                             const float* next_done, const float* next_true_done, float gamma, float gamma_lambda,
-                             float* advantages, float* returns, int T, int64_t N, void* stream) {
+template <typename ST>
+int gae_any(catppo_ctx* ctx, int kind, const ST* rewards, const ST* values, const ST* dones, const ST* true_dones,
+            const ST* next_value, const ST* next_done, const ST* next_true_done, float gamma, float gamma_lambda,
+            ST* advantages, ST* returns, int T, int64_t N, void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, kind >= CATPPO_GAE_CLEANRL && kind <= CATPPO_GAE_SKRL);
   CATPPO_CHECK_ARG(ctx, rewards && values && dones && next_value && advantages && returns);
@@ -134,26 +137,47 @@ extern "C" int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // wide path only when every (T,N) row starts 16-B aligned and there are enough envs to
-  // fill the chip with 4-env lanes (256 CUs x >=8 waves)
-  const bool wide = (N % 4 == 0) && N >= (int64_t)256 * 64 * 8 * 4 / 4 && aligned16(rewards) &&
+  // fill the chip with 16-B lanes (256 CUs x >=8 waves)
+  constexpr int WV = 16 / (int)sizeof(ST);
+  const bool wide = (N % WV == 0) && N >= (int64_t)256 * 64 * 8 && aligned16(rewards) &&
                     aligned16(values) && aligned16(dones) && aligned16(true_dones) && aligned16(next_value) &&
                     aligned16(next_done) && aligned16(next_true_done) && aligned16(advantages) &&
-                    aligned16(returns);
+                    aligned16(returns) && (N * sizeof(ST)) % 16 == 0;
   switch (kind) {
     case CATPPO_GAE_CLEANRL:
-      launch_gae<0>(wide, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma,
-                    gamma_lambda, advantages, returns, T, N, s);
+      launch_gae<0, ST>(wide, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma,
+                        gamma_lambda, advantages, returns, T, N, s);
       break;
     case CATPPO_GAE_RL_GAMES:
-      launch_gae<1>(wide, rewards, values, dones, nullptr, next_value, next_done, nullptr, gamma, gamma_lambda,
-                    advantages, returns, T, N, s);
+      launch_gae<1, ST>(wide, rewards, values, dones, nullptr, next_value, next_done, nullptr, gamma, gamma_lambda,
+                        advantages, returns, T, N, s);
       break;
     default:
-      launch_gae<2>(wide, rewards, values, dones, nullptr, next_value, nullptr, nullptr, gamma, gamma_lambda,
-                    advantages, returns, T, N, s);
+      launch_gae<2, ST>(wide, rewards, values, dones, nullptr, next_value, nullptr, nullptr, gamma, gamma_lambda,
+                        advantages, returns, T, N, s);
   }
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
+}
+
+}  // namespace
+
+extern "C" int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values,
+                             const float* dones, const float* true_dones, const float* next_value,
+                             const float* next_done, const float* next_true_done, float gamma, float gamma_lambda,
+                             float* advantages, float* returns, int T, int64_t N, void* stream) {
+  return gae_any<float>(ctx, kind, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma,
+                        gamma_lambda, advantages, returns, T, N, stream);
+}
+
+extern "C" int catppo_gae_f16(catppo_ctx* ctx, int kind, const void* rewards, const void* values, const void* dones,
+                              const void* true_dones, const void* next_value, const void* next_done,
+                              const void* next_true_done, float gamma, float gamma_lambda, void* advantages,
+                              void* returns, int T, int64_t N, void* stream) {
+  using h = _Float16;
+  return gae_any<h>(ctx, kind, (const h*)rewards, (const h*)values, (const h*)dones, (const h*)true_dones,
+                    (const h*)next_value, (const h*)next_done, (const h*)next_true_done, gamma, gamma_lambda,
+                    (h*)advantages, (h*)returns, T, N, stream);
 }
 
 extern "C" int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,

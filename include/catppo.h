@@ -197,6 +197,14 @@ int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* 
                   const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
                   float* returns, int T, int64_t N, void* stream);
 
+/* fp16 rollout planes (BASELINE config 5): every (T,N) plane and (N,) row is IEEE half; values are widened to fp32,
+ * the recurrence of `kind` runs in the same fp32 op order, advantages and returns (= fl32(A + v)) are rounded
+ * to half (RNE) when stored.  12 B (CleanRL) / 10 B (rl_games, skrl) per env-step. */
+int catppo_gae_f16(catppo_ctx* ctx, int kind, const void* rewards, const void* values, const void* dones,
+                   const void* true_dones, const void* next_value, const void* next_done,
+                   const void* next_true_done, float gamma, float gamma_lambda, void* advantages, void* returns,
+                   int T, int64_t N, void* stream);
+
 /* skrl whole-batch advantage normalisation (skrl/ppo.py:436): out = (A - mean(A)) / (std_unbiased(A) + 1e-8),
  * moments in fp64 (deterministic); out may alias advantages; stats (NULL ok) receives {mean, std + 1e-8}. */
 int catppo_adv_normalize(catppo_ctx* ctx, const float* advantages, int64_t n, float* out, float* stats,

@@ -602,3 +602,19 @@ def test_gae_full_size_slices_and_linearity(nat):
         out.append(a_)
     err = (out[0] + out[1] - out[2] - out[3]).abs().max().item()
     assert err < 2e-4, err
+
+
+@pytest.mark.parametrize("T,N,seed", [(24, 64, 2), (5, 1000, 4), (24, 262144, 5)])
+def test_gae_fp16_planes_bit_exact(nat, T, N, seed):
+    """fp16 rollout planes (BASELINE config 5): fp32 recurrence on the widened values, RNE to half on store"""
+    x = {k: v.astype(np.float16) for k, v in S.gae_inputs(seed, T, N).items()}
+    d = {k: dev(v) for k, v in x.items()}
+    adv = torch.empty(T, N, device="cuda", dtype=torch.float16)
+    ret = torch.empty_like(adv)
+    nat.gae_f16(d["rewards"], d["values"], d["dones"], d["true_dones"], d["next_value"], d["next_done"],
+                d["next_true_done"], 0.99, 0.95, adv, ret)
+    f = {k: v.astype(np.float32) for k, v in x.items()}
+    a, r = PO.gae_numpy_exact(f["rewards"], f["values"], f["dones"], f["true_dones"], f["next_value"], f["next_done"],
+                              f["next_true_done"], 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy(), a.astype(np.float16))
+    np.testing.assert_array_equal(ret.cpu().numpy(), r.astype(np.float16))

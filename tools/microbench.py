@@ -48,6 +48,16 @@ def main():
         out.append(dict(kernel="gae", T=T, N=N, us=us, GBps=byt / us / 1e3, frac_8TBps=byt / us / 1e3 / 8000))
         del x, adv, ret
 
+    # ---- GAE on fp16 planes (12 B per env-step)
+    for T, N in [(24, 32768), (24, 1 << 20), (48, 1 << 22)]:
+        x = [torch.rand(T, N, device=dev).half() for _ in range(4)]
+        nv, nd, ntd = (torch.rand(N, device=dev).half() for _ in range(3))
+        adv, ret = (torch.empty(T, N, device=dev, dtype=torch.float16) for _ in range(2))
+        us = timeit(lambda: nat.gae_f16(x[0], x[1], x[2], x[3], nv, nd, ntd, 0.99, 0.95, adv, ret), a.reps)
+        byt = 12 * T * N + 6 * N
+        out.append(dict(kernel="gae[fp16 planes]", T=T, N=N, us=us, GBps=byt / us / 1e3, frac_8TBps=byt / us / 1e3 / 8000))
+        del x, adv, ret
+
     # ---- CaT step
     for N, widths in [(4096, [12, 12, 1, 4, 12, 1]), (4096, [12, 12, 12, 12, 1, 4, 2, 1, 4, 1, 4, 12, 1]),
                       (32768, [12, 12, 12, 12, 1, 4, 2, 1, 4, 1, 4, 12, 1])]:
