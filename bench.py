@@ -40,6 +40,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no 2:1 sparsity)
 
 
 def fwd_macs(obs_dim, hidden, act_dim=12):
@@ -48,7 +49,7 @@ def fwd_macs(obs_dim, hidden, act_dim=12):
     return 2 * body + hidden[-1] * (act_dim + 1)
 
 
-def build(workload, seed, device_index):
+def build(workload, seed, device_index, mlp_precision="fp32"):
     import smoke_impl
     from cat_envs.shim import make
     from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
@@ -56,6 +57,7 @@ def build(workload, seed, device_index):
     task, env_cfg, agent_cfg = smoke_impl.make_cfgs(w["num_envs"], w["num_steps"], 16384, 5, 2000, w["hidden"],
                                                     w["six_terms"], obs_dim=w["obs_dim"], stream_steps=48, seed=seed)
     env_cfg.sim.device = f"cuda:{device_index}"
+    agent_cfg.mlp_precision = mlp_precision
     env = make(task, cfg=env_cfg)
     trainer = PPOTrainer(env, agent_cfg)
     return env, trainer, agent_cfg
@@ -150,6 +152,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mlp-precision", choices=("fp32", "bf16"), default="fp32",
+                    help="fp32 = the reference's numerics (the headline metric).  bf16 = hidden-layer GEMM operands "
+                         "rounded to bf16, fp32 accumulation / master weights (BASELINE config 5): NOT the parity mode")
     ap.add_argument("--seed", type=int, default=42)
     a = ap.parse_args()
 
@@ -170,7 +175,7 @@ def main():
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
 
     w = WORKLOADS[a.workload]
-    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local)
+    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision)
     nat = trainer.nat
 
     def barrier():
@@ -214,17 +219,20 @@ def main():
         M = 16384
         flops_per_launch = 3 * 2 * macs * M                       # fwd + bwd = 3x fwd, per minibatch
         ach = flops_per_launch / grad_us / 1e6
-        traffic = pmc_traffic(a.workload)
+        bf16 = a.mlp_precision == "bf16"
+        peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
+        traffic = None if bf16 else pmc_traffic(a.workload)
         out = {
             "metric": "env-steps/s CaT-PPO iteration (rollout + GAE + PPO update)", "value": value,
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if not bf16 else "bf16 GEMM operands, f32 accumulate/params (reduced precision: not the headline)",
+            "data": "synthetic",
             "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": w["num_envs"], "horizon": w["num_steps"],
                        "global_minibatch": M * world, "parallelism": f"env-sharded dp{world}, RCCL all-reduce of the flat gradient"},
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad (gather, 2x3 grouped fp32-MFMA GEMM launches fwd, "
                          "head+loss, split-K dW + dX GEMMs, partial reductions) per 16384-sample minibatch",
-                         "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS,
+                         "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "avg_launch_us": grad_us,
                          "flops_per_launch": flops_per_launch,
                          "traffic_source": None if traffic is None else

@@ -22,7 +22,7 @@ using gemm::Params;
 constexpr int kMaxA = 16;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
 constexpr float kEntConst = 1.41893853320467274178f;     // 0.5 + 0.5*log(2*pi)
-constexpr int kHeadRowsPerBlock = 32;                    // head_loss: 8 waves x 4 rows
+constexpr int kHeadRowsPerBlock = 32;                    // head_loss row tile
 constexpr int kGatherRows = 64;
 
 // ------------------------------------------------------------------------------- layout
@@ -404,9 +404,10 @@ struct HeadArgs {
   catppo_ppo_hparams hp;
 };
 
-static_assert(kHeadRowsPerBlock == 32, "8 waves x 4 rows per tile");
-constexpr int kHeadWaves = 8;        // waves per block
-constexpr int kHeadRowsPerWave = 4;  // rows of a tile handled by one wave
+// waves per block: a 32-row tile of a wide last layer (HL >= 256) fills the CU's LDS alone, so the block brings
+// its own parallelism (16 waves x 2 rows); narrower layers co-reside 2-3 blocks per CU and do better with 8 x 4
+template <int CPL>
+constexpr int head_waves() { return CPL >= 4 ? 16 : 8; }
 constexpr int kHeadMaxBlocks = 512;  // = number of weight-gradient partials folded afterwards (2 blocks per CU)
 
 // Heads + PPO loss + backward through the heads, one tile of 32 minibatch rows at a time:
@@ -417,7 +418,9 @@ constexpr int kHeadMaxBlocks = 512;  // = number of weight-gradient partials fol
 //           stay in registers across the tiles of the block => ONE partial per block, no per-wave
 //           reduction rounds
 template <int CPL>
-__global__ __launch_bounds__(kHeadWaves * 64, (CPL <= 4 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
+__global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
+  constexpr int kHeadWaves = head_waves<CPL>();
+  constexpr int kHeadRowsPerWave = kHeadRowsPerBlock / kHeadWaves;
   constexpr int HL = CPL * 64;
   constexpr int NT = kHeadWaves * 64;
   constexpr int NG = NT / HL >= 1 ? NT / HL : 1;       // phase-2 thread groups (HL <= 512)
@@ -964,7 +967,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       if (head_lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)head_lds);
-      kern<<<dim3(nbh), dim3(kHeadWaves * 64), head_lds, s>>>(g);
+      kern<<<dim3(nbh), dim3(head_waves<CPL>() * 64), head_lds, s>>>(g);
     });
     if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
     CATPPO_CHECK_LAUNCH(ctx);
