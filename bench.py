@@ -190,7 +190,7 @@ def main():
     # HIP events bracket every catppo_ppo_minibatch_grad call (the dominant kernel group) on the stream
     # it is enqueued on (torch's current stream)
     ev = []
-    orig = nat.ppo_minibatch_grad
+    orig = nat.ppo_minibatch_grad_packed
 
     def timed_grad(*args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -198,14 +198,14 @@ def main():
         orig(*args, **kw)
         e1.record()
         ev.append((e0, e1))
-    nat.ppo_minibatch_grad = timed_grad
+    nat.ppo_minibatch_grad_packed = timed_grad
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         trainer.run_iteration(log=False)
     barrier()
     dt = time.perf_counter() - t0
-    nat.ppo_minibatch_grad = orig
+    nat.ppo_minibatch_grad_packed = orig
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -230,8 +230,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": w["num_envs"], "horizon": w["num_steps"],
                        "global_minibatch": M * world, "parallelism": f"env-sharded dp{world}, RCCL all-reduce of the flat gradient"},
-            "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad (gather, 2x3 grouped fp32-MFMA GEMM launches fwd, "
-                         "head+loss, split-K dW + dX GEMMs, partial reductions) per 16384-sample minibatch",
+            "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (3 grouped fp32-MFMA forward GEMM launches, "
+                         "head+loss, paired split-K dW + dX GEMM launches, partial fold) per 16384-sample minibatch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "avg_launch_us": grad_us,
                          "flops_per_launch": flops_per_launch,

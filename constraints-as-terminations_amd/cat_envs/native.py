@@ -88,6 +88,10 @@ _SIGNATURES = {
     "catppo_value": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp]),
     "catppo_ppo_minibatch_grad": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_ppo_gather": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
+                                    _vp, _vp, _vp]),
+    "catppo_ppo_minibatch_grad_packed": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp,
+                                                   _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catppo_clip_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _f64, _i64, _vp]),
 }
 
@@ -375,6 +379,24 @@ class Native:
             self.h, C.byref(shape), C.byref(hp), _p(params), _p(b_obs), _p(b_actions), _p(b_logprobs),
             _p(b_advantages), _p(b_returns_n), _p(b_values_n), _p(mb_inds), mb_inds.numel(), _p(vrms_mean),
             _p(vrms_var), _p(adv_stats), _p(grad), _p(diag), self._stream()))
+
+    GATHER_ROWS = 64     # CATPPO_GATHER_ROWS
+
+    def ppo_gather(self, shape, b_obs, b_actions, b_logprobs, b_advantages, b_returns_n, b_values_n, inds, M, x_g,
+                   act_g, scal_g, adv_part_g):
+        """one launch: the whole permutation ``inds`` -> packed buffers, minibatch m = contiguous slice m"""
+        _chk(inds, torch.int64, "inds")
+        _chk(adv_part_g, torch.float64, "adv_part_g")
+        self._ok(self.lib.catppo_ppo_gather(
+            self.h, C.byref(shape), _p(b_obs), _p(b_actions), _p(b_logprobs), _p(b_advantages), _p(b_returns_n),
+            _p(b_values_n), _p(inds), inds.numel(), int(M), _p(x_g), _p(act_g), _p(scal_g), _p(adv_part_g),
+            self._stream()))
+
+    def ppo_minibatch_grad_packed(self, shape, hp: PpoHparams, params, x_mb, act_mb, scal_mb, adv_part_mb, M,
+                                  vrms_mean, vrms_var, adv_stats, grad, diag):
+        self._ok(self.lib.catppo_ppo_minibatch_grad_packed(
+            self.h, C.byref(shape), C.byref(hp), _p(params), _p(x_mb), _p(act_mb), _p(scal_mb), _p(adv_part_mb),
+            int(M), _p(vrms_mean), _p(vrms_var), _p(adv_stats), _p(grad), _p(diag), self._stream()))
 
     def clip_adam(self, params, grad, exp_avg, exp_avg_sq, n_flat, max_grad_norm, lr, beta1, beta2, eps, step):
         self._ok(self.lib.catppo_clip_adam(self.h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), int(n_flat),

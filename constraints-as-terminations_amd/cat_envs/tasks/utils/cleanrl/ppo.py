@@ -368,14 +368,23 @@ class PPOTrainer:
             parallel.allreduce_sum_(self._adv_mom)
             nat.adv_stats(self._adv_mom, E * n_mb, self._adv_stats_all)
         self.hp.adv_stats_external = int(exact_adv)
+        if not hasattr(self, "_x_g"):
+            # packed epoch buffers: one gather launch per epoch, minibatch k = contiguous slice k
+            self._parts = (M + nat.GATHER_ROWS - 1) // nat.GATHER_ROWS
+            self._x_g = torch.empty(B, self.Dp, device=self.device)
+            self._act_g = torch.empty(B, self.A, device=self.device)
+            self._scal_g = torch.empty(4 * B, device=self.device)
+            self._advp_g = torch.empty(n_mb * self._parts * 2, dtype=torch.float64, device=self.device)
         for epoch in range(E):
-            inds = perms[epoch]
+            nat.ppo_gather(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, perms[epoch], M, self._x_g,
+                           self._act_g, self._scal_g, self._advp_g)
             for k, start in enumerate(range(0, B, M)):
-                mb = inds[start:start + M]
-                self.hp.inv_global_batch = 1.0 / (mb.numel() * self.world)
+                m = min(M, B - start)
+                self.hp.inv_global_batch = 1.0 / (m * self.world)
                 adv_stats = self._adv_stats_all[epoch * n_mb + k] if exact_adv else None
-                nat.ppo_minibatch_grad(a.shape, self.hp, a.flat, b_obs, b_act, b_logp, b_adv, b_ret, b_val, mb,
-                                       vmean, vvar, adv_stats, self.grad, self.diag)
+                nat.ppo_minibatch_grad_packed(a.shape, self.hp, a.flat, self._x_g[start:], self._act_g[start:],
+                                              self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
+                                              vmean, vvar, adv_stats, self.grad, self.diag)
                 parallel.allreduce_sum_(self.grad)              # RCCL SUM of the flat gradient over xGMI
                 self.adam_step += 1
                 nat.clip_adam(a.flat, self.grad, self.exp_avg, self.exp_avg_sq, a.layout.n_flat,

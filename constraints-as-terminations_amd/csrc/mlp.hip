@@ -345,17 +345,31 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------- minibatch gather
+// grid = (row chunks of one minibatch, minibatches).  Minibatch m = samples inds[m*M .. m*M + M_m) lands in the
+// contiguous slices xmb[m*M ..], act[m*M ..], scal[4*m*M + {0,1,2,3}*M_m ..], adv_part[m][chunk][2].
 __global__ __launch_bounds__(256) void ppo_gather_kernel(const float* __restrict__ b_obs, const float* __restrict__ b_act,
                                                          const float* __restrict__ b_logp,
                                                          const float* __restrict__ b_adv,
                                                          const float* __restrict__ b_ret,
                                                          const float* __restrict__ b_val,
-                                                         const int64_t* __restrict__ inds, int64_t M, int Dp, int A,
-                                                         float* __restrict__ xmb, float* __restrict__ act,
-                                                         float* __restrict__ scal, double* __restrict__ adv_part) {
+                                                         const int64_t* __restrict__ inds, int64_t total, int64_t M,
+                                                         int Dp, int A, float* __restrict__ xmb,
+                                                         float* __restrict__ act, float* __restrict__ scal,
+                                                         double* __restrict__ adv_part) {
   __shared__ int64_t s_idx[kGatherRows];
-  const int64_t r0 = (int64_t)blockIdx.x * kGatherRows;
-  const int rows = (int)((M - r0) < kGatherRows ? (M - r0) : kGatherRows);
+  const int64_t m0 = (int64_t)blockIdx.y * M;                     // first sample of this minibatch
+  const int64_t Mm = (total - m0) < M ? (total - m0) : M;         // its size (the last one may be short)
+  const int64_t r0 = (int64_t)blockIdx.x * kGatherRows;           // row chunk inside the minibatch
+  if (r0 >= Mm) {
+    if (threadIdx.x == 0) {
+      adv_part[2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x)] = 0.0;
+      adv_part[2 * ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) + 1] = 0.0;
+    }
+    return;
+  }
+  const int rows = (int)((Mm - r0) < kGatherRows ? (Mm - r0) : kGatherRows);
+  inds += m0, xmb += m0 * Dp, act += m0 * A, scal += 4 * m0;
+  adv_part += 2 * (int64_t)blockIdx.y * gridDim.x;
   if (threadIdx.x < rows) s_idx[threadIdx.x] = inds[r0 + threadIdx.x];
   __syncthreads();
   const int q4 = Dp / 4;
@@ -372,10 +386,10 @@ __global__ __launch_bounds__(256) void ppo_gather_kernel(const float* __restrict
     if (threadIdx.x < rows) {
       const int64_t src = s_idx[threadIdx.x], dst = r0 + threadIdx.x;
       const float adv = b_adv[src];
-      scal[0 * M + dst] = b_logp[src];
-      scal[1 * M + dst] = adv;
-      scal[2 * M + dst] = b_ret[src];
-      scal[3 * M + dst] = b_val[src];
+      scal[0 * Mm + dst] = b_logp[src];
+      scal[1 * Mm + dst] = adv;
+      scal[2 * Mm + dst] = b_ret[src];
+      scal[3 * Mm + dst] = b_val[src];
       a1 = (double)adv;
       a2 = a1 * a1;
     }
@@ -899,6 +913,14 @@ extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, cons
   return CATPPO_OK;
 }
 
+namespace {
+// forward + losses + backward on an ALREADY GATHERED minibatch: xmb [M,Dp], act [M,A], scal [4][M]
+// {old log-prob, advantage, normalised return, normalised value}, adv_part [nbg][2] fp64 advantage moments
+int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_mlp_layout& L, MlpWs& w,
+                        const catppo_ppo_hparams* hp, const float* params, int64_t M, const float* vrms_mean,
+                        const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s);
+}  // namespace
+
 extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape* shape,
                                          const catppo_ppo_hparams* hp, const float* params, const float* b_obs,
                                          const float* b_actions, const float* b_logprobs,
@@ -913,6 +935,57 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
                             b_values_n && mb_inds && vrms_mean && vrms_var && grad && diag);
   CATPPO_CHECK_ARG(ctx, !hp->adv_stats_external || adv_stats != nullptr);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // 1. gather the minibatch (ppo.py:300-302,314,331-337 index with mb_inds)
+  hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), 1), dim3(256), 0, s, b_obs, b_actions,
+                     b_logprobs, b_advantages, b_returns_n, b_values_n, mb_inds, M, M, L.obs_pad, shape->act_dim,
+                     w.xmb, w.act, w.scal, w.adv_part);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return minibatch_grad_core(ctx, shape, L, w, hp, params, M, vrms_mean, vrms_var, adv_stats, grad, diag, s);
+}
+
+extern "C" int catppo_ppo_gather(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs,
+                                 const float* b_actions, const float* b_logprobs, const float* b_advantages,
+                                 const float* b_returns_n, const float* b_values_n, const int64_t* inds,
+                                 int64_t total, int64_t M, float* x_g, float* act_g, float* scal_g,
+                                 double* adv_part_g, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  catppo_mlp_layout L;
+  CATPPO_CHECK_ARG(ctx, shape && catppo_mlp_layout_of(shape, &L) == CATPPO_OK);
+  CATPPO_CHECK_ARG(ctx, b_obs && b_actions && b_logprobs && b_advantages && b_returns_n && b_values_n && inds);
+  CATPPO_CHECK_ARG(ctx, x_g && act_g && scal_g && adv_part_g && total >= 1 && M >= 1);
+  const int64_t n_mb = cdiv64(total, M);
+  CATPPO_CHECK_ARG(ctx, n_mb <= 65535);
+  hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), (unsigned)n_mb), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), b_obs, b_actions, b_logprobs, b_advantages, b_returns_n,
+                     b_values_n, inds, total, M, L.obs_pad, shape->act_dim, x_g, act_g, scal_g, adv_part_g);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_ppo_minibatch_grad_packed(catppo_ctx* ctx, const catppo_mlp_shape* shape,
+                                                const catppo_ppo_hparams* hp, const float* params,
+                                                const float* x_mb, const float* act_mb, const float* scal_mb,
+                                                const double* adv_part_mb, int64_t M, const float* vrms_mean,
+                                                const float* vrms_var, const float* adv_stats, float* grad,
+                                                float* diag, void* stream) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, M, true, &L, &w, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, hp && params && x_mb && act_mb && scal_mb && adv_part_mb && vrms_mean && vrms_var && grad &&
+                            diag);
+  CATPPO_CHECK_ARG(ctx, !hp->adv_stats_external || adv_stats != nullptr);
+  CATPPO_CHECK_ARG(ctx, (reinterpret_cast<uintptr_t>(x_mb) & 15) == 0);
+  // the kernels only read these: point the workspace view at the caller's gathered slices
+  w.xmb = const_cast<float*>(x_mb), w.act = const_cast<float*>(act_mb), w.scal = const_cast<float*>(scal_mb);
+  w.adv_part = const_cast<double*>(adv_part_mb);
+  return minibatch_grad_core(ctx, shape, L, w, hp, params, M, vrms_mean, vrms_var, adv_stats, grad, diag,
+                             static_cast<hipStream_t>(stream));
+}
+
+namespace {
+int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_mlp_layout& L, MlpWs& w,
+                        const catppo_ppo_hparams* hp, const float* params, int64_t M, const float* vrms_mean,
+                        const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s) {
   const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
   const int nbg = (int)cdiv64(M, kGatherRows);
   int nbh = (int)cdiv64(M, kHeadRowsPerBlock);
@@ -923,11 +996,6 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
       sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
   const int head_cap = 2 * head_lds > 160 * 1024 ? kHeadMaxBlocks / 2 : kHeadMaxBlocks;
   if (nbh > head_cap) nbh = head_cap;
-
-  // 1. gather the minibatch (ppo.py:300-302,314,331-337 index with mb_inds)
-  hipLaunchKernelGGL(ppo_gather_kernel, dim3(nbg), dim3(256), 0, s, b_obs, b_actions, b_logprobs, b_advantages,
-                     b_returns_n, b_values_n, mb_inds, M, L.obs_pad, A, w.xmb, w.act, w.scal, w.adv_part);
-  CATPPO_CHECK_LAUNCH(ctx);
 
   const int fv = fused_variant(shape);
   const int rpt = fv ? fused_rows(fv) : 0;
@@ -1075,6 +1143,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
 #undef CATPPO_HIP_OK
   return CATPPO_OK;
 }
+}  // namespace
 
 extern "C" int catppo_clip_adam(catppo_ctx* ctx, float* params, float* grad, float* exp_avg, float* exp_avg_sq,
                                 int64_t n_flat, float max_grad_norm, double lr, double beta1, double beta2,

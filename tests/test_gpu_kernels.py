@@ -618,3 +618,39 @@ def test_gae_fp16_planes_bit_exact(nat, T, N, seed):
                               f["next_true_done"], 0.99, 0.95)
     np.testing.assert_array_equal(adv.cpu().numpy(), a.astype(np.float16))
     np.testing.assert_array_equal(ret.cpu().numpy(), r.astype(np.float16))
+
+
+def test_epoch_gather_plus_packed_grad_equals_gathering_grad(nat):
+    """catppo_ppo_gather (one launch per epoch) + catppo_ppo_minibatch_grad_packed on slice k == catppo_ppo_minibatch_grad
+    on inds[k*M:(k+1)*M], bit for bit, including the short last minibatch (B = 2.5 minibatches)"""
+    from cat_envs import native
+    D, A, hidden, M = 45, 12, (256, 128), 1000
+    B = 2500
+    shape = native.shape_of(D, A, hidden)
+    lay = native.layout_of(shape)
+    c = _minibatch_case(D, A, hidden, B, B, 11)
+    params = torch.randn(lay.n_flat, device="cuda") * 0.05
+    obs_p = np.zeros((B, lay.obs_pad), np.float32)
+    obs_p[:, :D] = c["obs"]
+    bufs = [dev(obs_p), dev(c["act"]), dev(c["logp"]), dev(c["adv"]), dev(c["ret"]), dev(c["val"])]
+    inds = dev(c["inds"])
+    vm, vv = dev(np.array([c["vmean"]])), dev(np.array([c["vvar"]]))
+    parts = (M + nat.GATHER_ROWS - 1) // nat.GATHER_ROWS
+    n_mb = (B + M - 1) // M
+    x_g, act_g = torch.empty(B, lay.obs_pad, device="cuda"), torch.empty(B, A, device="cuda")
+    scal_g = torch.empty(4 * B, device="cuda")
+    advp = torch.empty(n_mb * parts * 2, dtype=torch.float64, device="cuda")
+    nat.mlp_reserve(shape, M)
+    nat.ppo_gather(shape, *bufs, inds, M, x_g, act_g, scal_g, advp)
+    np.testing.assert_array_equal(x_g.cpu().numpy(), obs_p[c["inds"]])
+    for k in range(n_mb):
+        start, m = k * M, min(M, B - k * M)
+        hp = native.PpoHparams(0.2, 0.001, 2.0, 1, 1, 1.0 / m, 0)
+        g1, d1 = torch.zeros(lay.n_flat, device="cuda"), torch.zeros(8, device="cuda")
+        g2, d2 = torch.zeros(lay.n_flat, device="cuda"), torch.zeros(8, device="cuda")
+        nat.ppo_minibatch_grad(shape, hp, params, *bufs, inds[start:start + m], vm, vv, None, g1, d1)
+        nat.ppo_minibatch_grad_packed(shape, hp, params, x_g[start:], act_g[start:], scal_g[4 * start:],
+                                      advp[2 * k * parts:], m, vm, vv, None, g2, d2)
+        np.testing.assert_array_equal(g1.cpu().numpy(), g2.cpu().numpy())
+        np.testing.assert_array_equal(d1.cpu().numpy(), d2.cpu().numpy())
+        assert np.abs(g1.cpu().numpy()).max() > 0

@@ -9,12 +9,12 @@ import csv
 import json
 import sys
 
-GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "seg_reduce_kernel", "ppo_gather_kernel")
+GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "seg_reduce_kernel")
 
 
 def per_launch(path):
     rows = list(csv.DictReader(open(path)))
-    n_mb = next(int(r["calls"]) for r in rows if "ppo_gather" in r["kernel"])
+    n_mb = next(int(r["calls"]) for r in rows if "head_loss_kernel" in r["kernel"])
     kib, detail = 0.0, {}
     for r in rows:
         if not any(k in r["kernel"] for k in GROUP):
@@ -31,7 +31,7 @@ def per_launch(path):
 
 f, n, fd, fg = per_launch(sys.argv[1])
 w, _, wd, wg = per_launch(sys.argv[2])
-out = {"kernel_group": "catppo_ppo_minibatch_grad", "minibatches_profiled": n,
+out = {"kernel_group": "catppo_ppo_minibatch_grad_packed", "minibatches_profiled": n,
        "FETCH_SIZE_KiB_per_launch_raw": f, "WRITE_SIZE_KiB_per_launch": w,
        "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
        "correction": "FETCH_SIZE x2 (gfx950, wide coalesced loads), WRITE_SIZE x1, KiB -> bytes",
