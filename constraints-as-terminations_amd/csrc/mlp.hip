@@ -22,7 +22,8 @@ using gemm::Params;
 constexpr int kMaxA = 16;
 constexpr float kHalfLog2Pi = 0.91893853320467274178f;   // log(sqrt(2*pi))
 constexpr float kEntConst = 1.41893853320467274178f;     // 0.5 + 0.5*log(2*pi)
-constexpr int kHeadRowsPerBlock = 32;                    // head_loss row tile
+constexpr int kHeadRowsPerBlock = 32;                    // head_loss row tile (16 rows when the last layer is 512 wide)
+inline int head_rows(int HL) { return HL > 256 ? 16 : 32; }   // both tiles + head weights must fit 160 KB of LDS
 constexpr int kGatherRows = 64;
 
 // ------------------------------------------------------------------------------- layout
@@ -101,7 +102,7 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
     return p;
   };
   const int nl = s->n_hidden, A = s->act_dim;
-  const int64_t nbg = cdiv64(M, kGatherRows), nbh = cdiv64(M, kHeadRowsPerBlock);
+  const int64_t nbg = cdiv64(M, kGatherRows), nbh = cdiv64(M, 16);   // upper bound of head_loss blocks
   // reduction partials first: the non-MLP calls use the front of the workspace too, but never
   // concurrently with an MLP call on the same stream
   w->xmb = (float*)take(sizeof(float) * M * L.obs_pad);
@@ -419,9 +420,10 @@ struct HeadArgs {
 };
 
 // waves per block: a 32-row tile of a wide last layer (HL >= 256) fills the CU's LDS alone, so the block brings
-// its own parallelism (16 waves x 2 rows); narrower layers co-reside 2-3 blocks per CU and do better with 8 x 4
+// its own parallelism (16 waves x 2 rows at HL = 256); narrower layers co-reside 2-3 blocks per CU and do better
+// with 8 x 4, and HL = 512 needs more than the 128 VGPRs a 1024-thread block may use
 template <int CPL>
-constexpr int head_waves() { return CPL >= 4 ? 16 : 8; }
+constexpr int head_waves() { return CPL == 4 ? 16 : 8; }   // CPL 8 needs > 128 VGPRs: 8 waves
 constexpr int kHeadMaxBlocks = 512;  // = number of weight-gradient partials folded afterwards (2 blocks per CU)
 
 // Heads + PPO loss + backward through the heads, one tile of 32 minibatch rows at a time:
@@ -434,12 +436,12 @@ constexpr int kHeadMaxBlocks = 512;  // = number of weight-gradient partials fol
 template <int CPL>
 __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
   constexpr int kHeadWaves = head_waves<CPL>();
-  constexpr int kHeadRowsPerWave = kHeadRowsPerBlock / kHeadWaves;
+  constexpr int TR = CPL == 8 ? 16 : kHeadRowsPerBlock;
+  constexpr int kHeadRowsPerWave = TR / kHeadWaves;
   constexpr int HL = CPL * 64;
   constexpr int NT = kHeadWaves * 64;
   constexpr int NG = NT / HL >= 1 ? NT / HL : 1;       // phase-2 thread groups (HL <= 512)
   constexpr int KPG = 16 / NG;                         // head outputs per group (16 slots)
-  constexpr int TR = kHeadRowsPerBlock;
   constexpr int VS = 15;                               // slot of the critic output; actions use slots 0..A-1
   // ALL shared memory lives in the dynamic region: a static __shared__ object in front of it would
   // shift its base off 16-B alignment and every ds_read_b128 below would be replayed (64 cycles each)
@@ -988,12 +990,13 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
                         const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s) {
   const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
   const int nbg = (int)cdiv64(M, kGatherRows);
-  int nbh = (int)cdiv64(M, kHeadRowsPerBlock);
+  const int TRh = head_rows(HL);
+  int nbh = (int)cdiv64(M, TRh);
   // head_loss blocks = weight-gradient partials folded afterwards.  Its LDS tile decides residency: when only one
   // block fits a CU (HL >= 256) a second round of blocks cannot overlap the first, so one block per CU walks
   // several tiles and pays the set-up (head weights, advantage statistics, partial flush) once.
   const size_t head_lds =
-      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)kHeadRowsPerBlock * HL + kHeadRowsPerBlock * 16 + 48 + 4);
+      sizeof(float) * ((size_t)16 * HL + 2 * (size_t)TRh * HL + TRh * 16 + 48 + 4);
   const int head_cap = 2 * head_lds > 160 * 1024 ? kHeadMaxBlocks / 2 : kHeadMaxBlocks;
   if (nbh > head_cap) nbh = head_cap;
 
