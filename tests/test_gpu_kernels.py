@@ -316,7 +316,8 @@ def unflatten_grad(shape, lay, flat, sd_like):
 
 @pytest.mark.parametrize("D,A,hidden,B", [(45, 12, (512, 256, 128), 96), (48, 12, (256, 256, 256), 4096),
                                            (45, 12, (512, 256, 128), 1000), (45, 12, (128, 512), 300),
-                                           (48, 7, (64,), 100)])
+                                           (48, 7, (64,), 100), (33, 15, (64, 128, 64, 128), 70),
+                                           (16, 1, (128, 64), 1)])
 def test_policy_act_vs_oracle_and_golden(nat, golden, D, A, hidden, B):
     from cat_envs import native
     shape = native.shape_of(D, A, hidden)
@@ -377,6 +378,8 @@ def _minibatch_case(D, A, hidden, Bsz, M, seed):
     (45, 12, (512, 256, 128), 98304, 16384, (True, True)),    # the reference's full minibatch
     (45, 12, (128, 512), 2048, 1024, (True, True)),           # widest supported last layer (8 columns per lane)
     (48, 7, (64,), 1024, 512, (True, True)),                  # narrowest: one hidden layer of 64, 7 actions
+    (33, 15, (64, 128, 64, 128), 1024, 300, (True, True)),    # deepest (4 hidden layers), widest action (15)
+    (16, 1, (128, 64), 512, 65, (True, False)),               # one action dimension, minibatch of 65
 ])
 def test_ppo_minibatch_grad_vs_autograd_oracle(nat, D, A, hidden, Bsz, M, flags):
     from cat_envs import native
