@@ -172,3 +172,15 @@ def test_train_and_play_entry_points(tmp_path):
                        cwd=tmp_path, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "model_3.pt" in r.stdout and "mean reward per step" in r.stdout
+
+
+def test_config5_env_count_full_constraints_7_envs_and_ragged():
+    """BASELINE config 5 env count (32768 envs, 13 terms with mixed hard/soft max_p: every term-kernel workgroup walks
+    8 tiles and emits one column-maximum partial) and a 7-env run (less than one 16-env tile): termination masks
+    bit-exact against the CPU oracle in both."""
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=32768, num_steps=2, minibatch=16384, epochs=1, iters=1,
+                                             six_terms=False)
+    smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=7, num_steps=5, minibatch=35, epochs=1, iters=2, six_terms=False)
+    smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
