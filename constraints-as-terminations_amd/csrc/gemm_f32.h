@@ -191,15 +191,20 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
 
   // data gradient: the activation the epilogue multiplies with does not depend on the contraction; with one
   // accumulator tile per wave (16 values per lane) fetch it now so its HBM latency hides behind the main loop
-  constexpr bool AUX_EARLY = EPI == EPI_MUL_DELU && TM * TN == 1;
-  float auxv[AUX_EARLY ? 16 : 1];
+  constexpr bool AUX_EARLY = EPI == EPI_MUL_DELU && TM * TN <= 2;
+  float auxv[AUX_EARLY ? TM * TN : 1][16];
   if constexpr (AUX_EARLY) {
-    const int gj = j0 + wn * WN + l31;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int gi = i0 + wm * WM + (r & 3) + 8 * (r >> 2) + 4 * h;
-      auxv[r] = (gi < p.I && gj < p.J) ? op.aux[(int64_t)gi * p.ldaux + gj] : 0.0f;
-    }
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int gj = j0 + wn * WN + tn * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int gi = i0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          auxv[tm * TN + tn][r] = (gi < p.I && gj < p.J) ? op.aux[(int64_t)gi * p.ldaux + gj] : 0.0f;
+        }
+      }
   }
 
   for (int s = 0; s < n_slabs; ++s) {
@@ -313,7 +318,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
           } else if (EPI == EPI_MUL_DELU) {
             float hact;
             if constexpr (AUX_EARLY) {
-              hact = auxv[r];
+              hact = auxv[tm * TN + tn][r];
             } else {
               hact = op.aux[(int64_t)gi * p.ldaux + gj];
             }
