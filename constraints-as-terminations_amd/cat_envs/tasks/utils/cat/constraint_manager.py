@@ -272,7 +272,8 @@ class ConstraintManager(ManagerBase):
         """descriptor table of the fused term kernel.  Built once and reused: the rows hold raw device pointers
         into the simulator's persistent state buffers (IsaacLab's ``data.*`` tensors are allocated once and
         updated in place) plus the term parameters, which only change through ``set_term_cfg`` (that drops
-        the cache).  ``self.term_cache = False`` re-describes every step."""
+        the cache).  Tables with a converted (copied) input are never cached; ``self.term_cache = False``
+        re-describes every step regardless."""
         cache = self._desc_cache if self.term_cache else None
         if cache is not None:
             return cache
@@ -288,8 +289,11 @@ class ConstraintManager(ManagerBase):
                 command = d.command
         arr = (native.TermDesc * len(rows))(*rows)
         self._desc_keep = keep
-        self._desc_cache = (arr, forces, H, B, command)
-        return self._desc_cache
+        table = (arr, forces, H, B, command)
+        # cache only tables whose pointers aim at the simulator's own buffers: a term input that needed a dtype /
+        # layout conversion was COPIED by describe(), and a cached pointer to that copy would go stale
+        self._desc_cache = table if all(d.cacheable for d in keep) else None
+        return table
 
     def compute(self, reward: torch.Tensor | None = None, reset_mask: torch.Tensor | None = None,
                 dones: torch.Tensor | None = None) -> torch.Tensor:

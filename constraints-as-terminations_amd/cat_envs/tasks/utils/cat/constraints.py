@@ -20,8 +20,11 @@ from cat_envs.shim import SceneEntityCfg
 
 
 class TermDescription:
-    """one descriptor row + the tensors it points to (kept alive while the row is in use)"""
-    __slots__ = ("c", "width", "is_bool", "forces", "command", "_keep")
+    """one descriptor row + the tensors it points to (kept alive while the row is in use).
+
+    ``cacheable``: every pointer in the row aims at the caller's own storage (no dtype / layout conversion had to
+    make a copy), so the row stays valid for as long as the simulator updates those buffers in place."""
+    __slots__ = ("c", "width", "is_bool", "forces", "command", "cacheable", "_keep")
 
     def __init__(self, kind, width, ids, limit=0.0, aux=0.0, x=None, y=None, forces=None, command=None,
                  is_bool=False):
@@ -30,15 +33,23 @@ class TermDescription:
         for i, v in enumerate(ids):
             d.ids[i] = int(v)
         d.limit, d.aux = float(limit), float(aux)
+        same = True
         if x is not None:
-            x = _rowmajor(x)
+            x0, x = x, _rowmajor(x)
+            same &= x.data_ptr() == x0.data_ptr() and x.dtype == x0.dtype
             d.x, d.x_ld = x.data_ptr(), x.stride(0)
         if y is not None:
-            y = _rowmajor(y)
+            y0, y = y, _rowmajor(y)
+            same &= y.data_ptr() == y0.data_ptr() and y.dtype == y0.dtype
             d.y, d.y_ld = y.data_ptr(), y.stride(0)
         self.c, self.width, self.is_bool = d, width, is_bool
         self.forces = None if forces is None else _dense(forces)
         self.command = None if command is None else _dense(command)
+        if forces is not None:
+            same &= self.forces.data_ptr() == forces.data_ptr() and self.forces.dtype == forces.dtype
+        if command is not None:
+            same &= self.command.data_ptr() == command.data_ptr() and self.command.dtype == command.dtype
+        self.cacheable = bool(same)
         self._keep = (x, y)
 
 

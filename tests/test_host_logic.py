@@ -197,3 +197,18 @@ def test_c_oracle_gae_vs_reference_ppo_run(golden):
                    C.c_float(0.99 * 0.95), _fp(adv), _fp(ret), T, C.c_int64(N))
     np.testing.assert_array_equal(adv, g["it0_advantages"])
     np.testing.assert_array_equal(ret, g["it0_returns"])
+
+
+def test_term_descriptor_rows_are_cached_only_when_they_alias_the_simulator_buffers():
+    """a descriptor row holds raw pointers: it may be reused across steps only if describe() did not have to copy
+    (dtype / layout conversion) any of its inputs"""
+    import torch
+    from cat_envs.tasks.utils.cat.constraints import TermDescription
+    x = torch.zeros(8, 12)
+    assert TermDescription(0, 12, list(range(12)), limit=1.0, x=x).cacheable
+    assert TermDescription(0, 4, [0, 1, 2, 3], limit=1.0, x=x[:, 2:9]).cacheable            # a column view is fine
+    assert not TermDescription(0, 12, list(range(12)), limit=1.0, x=x.double()).cacheable    # converted -> copied
+    assert not TermDescription(0, 8, list(range(8)), limit=1.0, x=torch.zeros(12, 8).t()).cacheable   # transposed
+    y = torch.zeros(8, 12)
+    assert TermDescription(1, 12, list(range(12)), limit=1.0, x=x, y=y).cacheable
+    assert not TermDescription(1, 12, list(range(12)), limit=1.0, x=x, y=y.half()).cacheable
