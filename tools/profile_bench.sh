@@ -24,6 +24,15 @@ for C in FETCH_SIZE WRITE_SIZE; do
   DB=$(run_pass "pmc_$C" --pmc "$C")
   [ -n "$DB" ] && python tools/rocpd_pmc.py "$DB" > "$OUT/${TAG}_pmc_${C}_${WL}.csv"
 done
+# SQ passes (8 SQ slots each): where the waves of every kernel spend their cycles, MFMA busy time, LDS conflicts
+if [ "${SQ_PASSES:-1}" = "1" ]; then
+  DB=$(run_pass pmc_sq1 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
+       SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT)
+  [ -n "$DB" ] && python tools/rocpd_pmc.py "$DB" > "$OUT/${TAG}_pmc_sq1_${WL}.csv"
+  DB=$(run_pass pmc_sq2 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE \
+       SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_WAVES)
+  [ -n "$DB" ] && python tools/rocpd_pmc.py "$DB" > "$OUT/${TAG}_pmc_sq2_${WL}.csv"
+fi
 if [ -s "$OUT/${TAG}_pmc_FETCH_SIZE_${WL}.csv" ] && [ -s "$OUT/${TAG}_pmc_WRITE_SIZE_${WL}.csv" ]; then
   python tools/pmc_group_traffic.py "$OUT/${TAG}_pmc_FETCH_SIZE_${WL}.csv" "$OUT/${TAG}_pmc_WRITE_SIZE_${WL}.csv" \
     > "$OUT/${TAG}_pmc_traffic_${WL}.json"
