@@ -78,6 +78,17 @@ class RunningMeanStd(nn.Module):
         else:
             nat.rms_update(rows, n, d, rows.stride(0), self.running_mean, self.running_var, self.count)
 
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        """Chan merge of externally computed batch moments (reference ppo.py:33-45).  Not on the training path -
+        ``update()`` fuses the moment pass and this merge on the device - so plain tensor ops, in place."""
+        m, v, c = update_mean_var_count_from_moments(self.running_mean, self.running_var, self.count,
+                                                     torch.as_tensor(batch_mean, device=self.running_mean.device),
+                                                     torch.as_tensor(batch_var, device=self.running_mean.device),
+                                                     batch_count)
+        self.running_mean.copy_(m)
+        self.running_var.copy_(v)
+        self.count.copy_(c)
+
     def normalize_into(self, rows: torch.Tensor, out: torch.Tensor, update: bool = True):
         """rows (n,d) with unit inner stride -> out (n,d') written in place (d' >= d, padding untouched)"""
         if update:
@@ -85,6 +96,16 @@ class RunningMeanStd(nn.Module):
         n, d = rows.shape
         native.get(rows.device).rms_normalize(rows, n, d, rows.stride(0), self.running_mean, self.running_var,
                                               self.epsilon, out, out.stride(0))
+
+
+def update_mean_var_count_from_moments(mean, var, count, batch_mean, batch_var, batch_count):
+    """(new_mean, new_var, new_count) of Chan's parallel merge, in the reference's operation order
+    (ppo.py:48-62): ``M2 = var*count + batch_var*batch_count + delta^2 * count * batch_count / tot``."""
+    delta = batch_mean - mean
+    tot_count = count + batch_count
+    new_mean = mean + delta * batch_count / tot_count
+    m2 = var * count + batch_var * batch_count + torch.square(delta) * count * batch_count / tot_count
+    return new_mean, m2 / tot_count, tot_count
 
 
 def layer_init(layer, std=np.sqrt(2), bias_const=0.0):

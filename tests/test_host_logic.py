@@ -212,3 +212,25 @@ def test_term_descriptor_rows_are_cached_only_when_they_alias_the_simulator_buff
     y = torch.zeros(8, 12)
     assert TermDescription(1, 12, list(range(12)), limit=1.0, x=x, y=y).cacheable
     assert not TermDescription(1, 12, list(range(12)), limit=1.0, x=x, y=y.half()).cacheable
+
+
+def test_update_from_moments_matches_the_reference_running_mean_std(golden):
+    """module-level update_mean_var_count_from_moments / RunningMeanStd.update_from_moments (reference ppo.py:33-62)
+    fed torch batch moments reproduce the states the reference's RunningMeanStd went through (tests/golden/rms.npz)"""
+    import numpy as np
+    import torch
+    from cat_envs.tasks.utils.cleanrl.ppo import RunningMeanStd, update_mean_var_count_from_moments
+    g = golden("rms")
+    rs = np.random.RandomState(int(g["seed"]))
+    xs = (rs.standard_normal((30, 64, 45)) * rs.uniform(0.1, 5, 45) + rs.uniform(-2, 2, 45)).astype(np.float32)
+    rms = RunningMeanStd(shape=(45,), device="cpu")
+    m, v, c = torch.zeros(45), torch.ones(45), torch.ones(())
+    for i in range(30):
+        x = torch.from_numpy(xs[i])
+        bm, bv = x.mean(0), x.var(0, correction=0)
+        rms.update_from_moments(bm, bv, x.shape[0])
+        m, v, c = update_mean_var_count_from_moments(m, v, c, bm, bv, x.shape[0])
+        st = np.concatenate([rms.running_mean.numpy(), rms.running_var.numpy(), rms.count.numpy().reshape(1)])
+        np.testing.assert_allclose(st, g["vec_state"][i], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(m.numpy(), rms.running_mean.numpy())
+    np.testing.assert_array_equal(v.numpy(), rms.running_var.numpy())
