@@ -96,6 +96,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _lib = None
 _contexts: dict = {}
 
@@ -181,6 +182,7 @@ class Native:
         if device.type != "cuda":
             raise RuntimeError(f"device {device} is not a HIP device; there is no CPU fallback")
         self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self._dev_index = int(self.device.index)
         h = _vp()
         rc = self.lib.catppo_create(self.device.index, C.byref(h))
         if rc != 0:
@@ -198,6 +200,10 @@ class Native:
 
     # ------------------------------------------------------------------ plumbing
     def _stream(self):
+        # raw hipStream_t of torch's current stream on this device.  The private accessor is ~15x cheaper than
+        # torch.cuda.current_stream(): 14 library calls per env step made the public one 40 % of the host time
+        if _raw_stream is not None:
+            return _raw_stream(self._dev_index)
         return torch.cuda.current_stream(self.device).cuda_stream
 
     def _ok(self, rc: int):
