@@ -105,6 +105,10 @@ def get(device=None) -> "Native":
     """process-wide context per HIP device (the manager, the env and PPO share one workspace and
     therefore one stream order)"""
     import torch as _t
+    if isinstance(device, _t.device) and device.index is not None:      # fast path: called several times per env step
+        ctx = _contexts.get(device.index)
+        if ctx is not None:
+            return ctx
     if not _t.cuda.is_available():
         raise RuntimeError("no HIP device visible: the CaT-PPO hot path runs on MI355X (gfx950) only; "
                            "there is no CPU fallback")

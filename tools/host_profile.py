@@ -21,4 +21,4 @@ for _ in range(5):
     trainer.rollout()
     torch.cuda.synchronize()
 pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
