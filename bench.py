@@ -37,6 +37,13 @@ WORKLOADS = {
     # the reference's real shapes
     "reference": dict(num_envs=4096, num_steps=24, obs_dim=45, hidden=(512, 256, 128), six_terms=False,
                       desc="4096 envs x 24, Solo12 45-d obs, 13 ConstraintTerms (78 cols), 512/256/128 MLPs, 5 epochs x 6 minibatches of 16384"),
+    # the other BASELINE.json configs (parity-test cases; measured for orientation, never the headline line)
+    "cfg3_shard": dict(num_envs=2048, num_steps=24, obs_dim=45, hidden=(512, 256, 128), six_terms=False, minibatch=2048,
+                       desc="one rank's share of config 3: 2048 envs x 24, full ConstraintsCfg, 512/256/128 MLPs, minibatches of 2048"),
+    "cfg4": dict(num_envs=4096, num_steps=48, obs_dim=235, hidden=(256, 256, 256), six_terms=True,
+                 desc="4096 envs x 48, 235-d obs (48 + 187 height scan), 6 ConstraintTerms, 3x256 MLP, minibatches of 16384"),
+    "cfg5_envs": dict(num_envs=32768, num_steps=24, obs_dim=48, hidden=(256, 256, 256), six_terms=False,
+                      desc="32768 envs x 24, 48-d obs, 13 ConstraintTerms with mixed hard/soft max_p, 3x256 MLP, minibatches of 16384"),
 }
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
@@ -54,7 +61,7 @@ def build(workload, seed, device_index, mlp_precision="fp32"):
     from cat_envs.shim import make
     from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
     w = WORKLOADS[workload]
-    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(w["num_envs"], w["num_steps"], 16384, 5, 2000, w["hidden"],
+    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(w["num_envs"], w["num_steps"], w.get("minibatch", 16384), 5, 2000, w["hidden"],
                                                     w["six_terms"], obs_dim=w["obs_dim"], stream_steps=48, seed=seed)
     env_cfg.sim.device = f"cuda:{device_index}"
     agent_cfg.mlp_precision = mlp_precision
@@ -108,7 +115,8 @@ def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=15.0):
     tm = orc.timers
     steps = w["num_envs"] * w["num_steps"] * n
     return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full iterations of {w['num_envs']}x{w['num_steps']} (5 epochs x 6 minibatches of 16384) "
+            "sample": f"{n} full iterations of {w['num_envs']}x{w['num_steps']} (5 epochs, minibatches of "
+                      f"{min(w.get('minibatch', 16384), w['num_envs'] * w['num_steps'])}) "
                       f"after 1 warm-up iteration, {dt:.1f} s wall",
             "phase_ms_per_iteration": {"rollout_fwd_and_env": 1e3 * tm["rollout"] / n, "cat_env_step": 1e3 * tm["env"] / n,
                                        "gae": 1e3 * tm["gae"] / n, "update": 1e3 * tm["update"] / n}}
@@ -216,7 +224,7 @@ def main():
     if rank == 0:
         grad_us = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
         macs = fwd_macs(w["obs_dim"], w["hidden"])
-        M = 16384
+        M = min(w.get("minibatch", 16384), w["num_envs"] * w["num_steps"])
         flops_per_launch = 3 * 2 * macs * M                       # fwd + bwd = 3x fwd, per minibatch
         ach = flops_per_launch / grad_us / 1e6
         bf16 = a.mlp_precision == "bf16"
@@ -231,7 +239,7 @@ def main():
             "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": w["num_envs"], "horizon": w["num_steps"],
                        "global_minibatch": M * world, "parallelism": f"env-sharded dp{world}, RCCL all-reduce of the flat gradient"},
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (3 grouped fp32-MFMA forward GEMM launches, "
-                         "head+loss, paired split-K dW + dX GEMM launches, partial fold) per 16384-sample minibatch",
+                         "head+loss, paired split-K dW + dX GEMM launches, partial fold) per " + str(M) + "-sample minibatch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic, "avg_launch_us": grad_us,
                          "flops_per_launch": flops_per_launch,
