@@ -52,91 +52,91 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
   for (int c = threadIdx.x; c < K; c += kThreads) cmax[c] = -__builtin_inff();
   const int64_t n_tiles = (N + kRows - 1) / kRows;
   for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
-  const int64_t r0 = tl * kRows;
-  const int rows = (int)((N - r0) < kRows ? (N - r0) : kRows);
+    const int64_t r0 = tl * kRows;
+    const int rows = (int)((N - r0) < kRows ? (N - r0) : kRows);
 
-  for (int t = wave; t < tab.n; t += kThreads / 64) {
-    const catppo_term_desc& d = tab.d[t];
-    const int W = d.width;
-    const int col0 = tab.off[t];
-    for (int w = lane; w < rows * W; w += 64) {
-      const int e = w / W, j = w - e * W;
-      const int64_t env = r0 + e;
-      float out = 0.0f;
-      switch (d.kind) {
-        case CATPPO_TERM_ABS_LIMIT: {
-          out = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
-        } break;
-        case CATPPO_TERM_ABS_DIFF_LIMIT: {
-          const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
-          out = fabsf(df) - d.limit;
-        } break;
-        case CATPPO_TERM_ABS_DIFF_LIMIT_GATE_CMDY: {
-          const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
-          const float c = fabsf(df) - d.limit;
-          const float gate = fabsf(command[env * cld + 1]) < d.aux ? 1.0f : 0.0f;
-          out = c * gate;
-        } break;
-        case CATPPO_TERM_GREATER: {
-          out = d.x[env * d.x_ld + d.ids[0]] > d.limit ? 1.0f : 0.0f;
-        } break;
-        case CATPPO_TERM_CONTACT_ANY: {
-          bool any = false;
-          for (int b = 0; b < d.n_ids; ++b) any = any || (force_peak(forces, fstride, env, H, B, d.ids[b]) > d.limit);
-          out = any ? 1.0f : 0.0f;
-        } break;
-        case CATPPO_TERM_NORM2_LIMIT: {
-          const float a = d.x[env * d.x_ld + 0], b = d.x[env * d.x_ld + 1];
-          float s = a * a;
-          s = s + b * b;
-          out = sqrtf(s) - d.limit;
-        } break;
-        case CATPPO_TERM_AIR_TIME: {
-          const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
-          float c = d.limit - d.x[env * d.x_ld + d.ids[j]];
-          c = c * d.y[env * d.y_ld + d.ids[j]];
-          out = c * gate;
-        } break;
-        case CATPPO_TERM_N_FOOT_CONTACT: {
-          int n = 0;
-          for (int b = 0; b < d.n_ids; ++b) n += force_peak(forces, fstride, env, H, B, d.ids[b]) > 1.0f ? 1 : 0;
-          int diff = n - (int)d.limit;
-          diff = diff < 0 ? -diff : diff;
-          const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
-          out = (float)diff * gate;
-        } break;
-        case CATPPO_TERM_ACTION_RATE: {
-          const float df = fabsf(d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]]);
-          out = df / d.aux - d.limit;
-        } break;
-        case CATPPO_TERM_FORCE_LIMIT: {
-          out = force_peak(forces, fstride, env, H, B, d.ids[j]) - d.limit;
-        } break;
-        case CATPPO_TERM_LIMIT_MINUS: {
-          out = d.limit - d.x[env * d.x_ld + d.ids[0]];
-        } break;
-        case CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT: {
-          const float c = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
-          const float gate = norm3(command + env * cld) < d.aux ? 1.0f : 0.0f;
-          out = c * gate;
-        } break;
-        default:
-          break;
+    for (int t = wave; t < tab.n; t += kThreads / 64) {
+      const catppo_term_desc& d = tab.d[t];
+      const int W = d.width;
+      const int col0 = tab.off[t];
+      for (int w = lane; w < rows * W; w += 64) {
+        const int e = w / W, j = w - e * W;
+        const int64_t env = r0 + e;
+        float out = 0.0f;
+        switch (d.kind) {
+          case CATPPO_TERM_ABS_LIMIT: {
+            out = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
+          } break;
+          case CATPPO_TERM_ABS_DIFF_LIMIT: {
+            const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
+            out = fabsf(df) - d.limit;
+          } break;
+          case CATPPO_TERM_ABS_DIFF_LIMIT_GATE_CMDY: {
+            const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
+            const float c = fabsf(df) - d.limit;
+            const float gate = fabsf(command[env * cld + 1]) < d.aux ? 1.0f : 0.0f;
+            out = c * gate;
+          } break;
+          case CATPPO_TERM_GREATER: {
+            out = d.x[env * d.x_ld + d.ids[0]] > d.limit ? 1.0f : 0.0f;
+          } break;
+          case CATPPO_TERM_CONTACT_ANY: {
+            bool any = false;
+            for (int b = 0; b < d.n_ids; ++b) any = any || (force_peak(forces, fstride, env, H, B, d.ids[b]) > d.limit);
+            out = any ? 1.0f : 0.0f;
+          } break;
+          case CATPPO_TERM_NORM2_LIMIT: {
+            const float a = d.x[env * d.x_ld + 0], b = d.x[env * d.x_ld + 1];
+            float s = a * a;
+            s = s + b * b;
+            out = sqrtf(s) - d.limit;
+          } break;
+          case CATPPO_TERM_AIR_TIME: {
+            const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
+            float c = d.limit - d.x[env * d.x_ld + d.ids[j]];
+            c = c * d.y[env * d.y_ld + d.ids[j]];
+            out = c * gate;
+          } break;
+          case CATPPO_TERM_N_FOOT_CONTACT: {
+            int n = 0;
+            for (int b = 0; b < d.n_ids; ++b) n += force_peak(forces, fstride, env, H, B, d.ids[b]) > 1.0f ? 1 : 0;
+            int diff = n - (int)d.limit;
+            diff = diff < 0 ? -diff : diff;
+            const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
+            out = (float)diff * gate;
+          } break;
+          case CATPPO_TERM_ACTION_RATE: {
+            const float df = fabsf(d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]]);
+            out = df / d.aux - d.limit;
+          } break;
+          case CATPPO_TERM_FORCE_LIMIT: {
+            out = force_peak(forces, fstride, env, H, B, d.ids[j]) - d.limit;
+          } break;
+          case CATPPO_TERM_LIMIT_MINUS: {
+            out = d.limit - d.x[env * d.x_ld + d.ids[0]];
+          } break;
+          case CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT: {
+            const float c = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
+            const float gate = norm3(command + env * cld) < d.aux ? 1.0f : 0.0f;
+            out = c * gate;
+          } break;
+          default:
+            break;
+        }
+        tile[e * K + col0 + j] = out;
       }
-      tile[e * K + col0 + j] = out;
     }
-  }
-  __syncthreads();
-  float* dst = cstr + r0 * K;
-  for (int e = threadIdx.x; e < rows * K; e += kThreads) dst[e] = tile[e];
-  if (colmax_partial != nullptr) {
-    for (int c = threadIdx.x; c < K; c += kThreads) {
-      float m = cmax[c];
-      for (int r = 0; r < rows; ++r) m = nanmax(m, tile[r * K + c]);
-      cmax[c] = m;
+    __syncthreads();
+    float* dst = cstr + r0 * K;
+    for (int e = threadIdx.x; e < rows * K; e += kThreads) dst[e] = tile[e];
+    if (colmax_partial != nullptr) {
+      for (int c = threadIdx.x; c < K; c += kThreads) {
+        float m = cmax[c];
+        for (int r = 0; r < rows; ++r) m = nanmax(m, tile[r * K + c]);
+        cmax[c] = m;
+      }
     }
-  }
-  __syncthreads();
+    __syncthreads();
   }
   if (colmax_partial != nullptr)
     for (int c = threadIdx.x; c < K; c += kThreads) colmax_partial[(int64_t)blockIdx.x * K + c] = cmax[c];
