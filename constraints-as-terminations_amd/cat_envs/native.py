@@ -66,6 +66,8 @@ _SIGNATURES = {
     "catppo_cat_terms_step": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
                                         _i32, _vp, _vp, _f32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),
+    "catppo_cat_terms_colmax": (C.c_int, [_vp, C.POINTER(TermDesc), _i32, _i64, _vp, _i64, _i32, _i32, _vp, _i32, _vp,
+                                          _i32, _vp, _vp]),
     "catppo_env_pre_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                       _vp]),
     "catppo_rollout_store": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -264,6 +266,14 @@ class Native:
             C.cast(term_off_host, _vp), C.cast(term_dp_host, _vp), f32(min_p), f32(tau), f32(1.0 - tau),
             int(bool(first_call)), _p(rm), _p(reward), _p(reset_mask), _p(cstr_prob), _p(dones), _p(ep_viol),
             _p(ep_prob), _p(probs), self._stream()))
+
+    def cat_terms_colmax(self, descs, forces, H, B, command, cstr, colmax):
+        """terms -> cstr and the local column maxima (env-sharded path: all-reduce MAX, then cat_apply)"""
+        N, K = cstr.shape
+        fstride = forces.stride(0) if forces is not None else 0
+        cld = command.stride(0) if command is not None else 0
+        self._ok(self.lib.catppo_cat_terms_colmax(self.h, descs, len(descs), N, _p(forces), fstride, int(H), int(B),
+                                                  _p(command), cld, _p(cstr), K, _p(colmax), self._stream()))
 
     def cat_reset(self, ep_viol, ep_prob, episode_length, mask, out, prev=None):
         n_terms, N = ep_viol.shape

@@ -311,6 +311,7 @@ class ConstraintManager(ManagerBase):
         sharded = group is not None and parallel.active(group)
         dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
         args = dict(reward=reward, reset_mask=reset_mask, dones=dones, probs=cat._p_probs)
+        have_colmax = False
         if self._fused:
             descs, forces, H, B, command = self._describe_terms()
             if not sharded:
@@ -318,7 +319,10 @@ class ConstraintManager(ManagerBase):
                                    cat._p_first, cat._p_rm, self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)
                 cat._p_first = False
                 return self._cstr_prob_buf
-            nat.cat_terms(descs, self.num_envs, forces, H, B, command, cat._p_cstr)
+            if not hasattr(self, "_colmax"):
+                self._colmax = torch.zeros_like(cat._p_rm)
+            nat.cat_terms_colmax(descs, forces, H, B, command, cat._p_cstr, self._colmax)
+            have_colmax = True
         else:
             off = 0
             for cfg, w in zip(self._term_cfgs, self._widths):
@@ -328,7 +332,8 @@ class ConstraintManager(ManagerBase):
         if sharded:
             if not hasattr(self, "_colmax"):
                 self._colmax = torch.zeros_like(cat._p_rm)
-            nat.cat_colmax(cat._p_cstr, self._colmax)
+            if not have_colmax:
+                nat.cat_colmax(cat._p_cstr, self._colmax)
             parallel.allreduce_max_(self._colmax, group)
             nat.cat_apply(cat._p_cstr, self._term_off, dp, cat.min_p, cat.tau, cat._p_first, self._colmax, cat._p_rm,
                           self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)

@@ -275,6 +275,26 @@ extern "C" int catppo_cat_colmax(catppo_ctx* ctx, const float* cstr, int64_t N, 
   return CATPPO_OK;
 }
 
+extern "C" int catppo_cat_terms_colmax(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
+                                       const float* forces, int64_t forces_env_stride, int H, int B,
+                                       const float* command, int command_ld, float* cstr, int K, float* colmax,
+                                       void* stream) {
+  if (int rc = check_common(ctx, cstr, N, K, n_terms)) return rc;
+  CATPPO_CHECK_ARG(ctx, desc && colmax);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WsCarver ws(ctx);
+  float* partial = ws.take<float>((uint64_t)256 * K);
+  CATPPO_NEED_WS(ctx, partial);
+  int nblk = 0;
+  if (int rc = catppo_internal_launch_terms(ctx, desc, n_terms, N, forces, forces_env_stride, H, B, command,
+                                            command_ld, cstr, K, partial, &nblk, s))
+    return rc;
+  hipLaunchKernelGGL(cat_reduce_ema, dim3(1), dim3(kThreads), 0, s, partial, nblk, K, colmax, (float*)nullptr, 0, 0,
+                     0.0f, 0.0f);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
 extern "C" int catppo_cat_apply(catppo_ctx* ctx, const float* cstr, int64_t N, int K, const int32_t* term_off,
                                 int n_terms, const float* term_dp, float min_p, float tau, float one_minus_tau,
                                 int first_call, const float* colmax, float* rm, float* reward,

@@ -148,6 +148,12 @@ int catppo_cat_terms_step(catppo_ctx* ctx, const catppo_term_desc* desc, int n_t
                           const uint8_t* reset_mask, float* cstr_prob, float* dones, float* ep_viol,
                           float* ep_prob, float* probs, void* stream);
 
+/* Env-sharded variant of the same fusion: terms -> cstr plus the local (floored) column maxima in two launches;
+ * all-reduce `colmax` with MAX, then catppo_cat_apply. */
+int catppo_cat_terms_colmax(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,
+                            const float* forces, int64_t forces_env_stride, int H, int B, const float* command,
+                            int command_ld, float* cstr, int K, float* colmax, void* stream);
+
 /* ---- env-step bookkeeping, fused ------------------------------------------------------------
  * catppo_env_pre_step: process_action (prev <- action, action <- action_in, [N,A]); episode_length += 1;
  *   time_outs = episode_length >= max_episode_length; terminated = hard_reset > 0.5; reset = either;
