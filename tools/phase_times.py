@@ -19,6 +19,10 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     torch.cuda.set_device(0)
+    if os.environ.get("CATPPO_FORCE_DIST") == "1":        # every exchange point active, RCCL world of size 1
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29534"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", 0))
     env, trainer, agent_cfg = bench.build(a.workload, 42, 0)
     for _ in range(3):
         trainer.run_iteration(log=False)
