@@ -54,7 +54,14 @@ __global__ __launch_bounds__(256) void gae_scan(const ST* __restrict__ rew, cons
                                                 const ST* __restrict__ next_tdone, float gamma, float gl,
                                                 ST* __restrict__ adv, ST* __restrict__ ret, int T,
                                                 int64_t N) {
-  const int64_t env = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  // XCD-aware block order (speed only): workgroup b runs on XCD b % 8 and every XCD has its own L2 / TLB; give each
+  // XCD one contiguous eighth of the env axis so that it touches one page (not eight) per row of every plane
+  int64_t blk = blockIdx.x;
+  {
+    const int64_t nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = blk & 7;
+    blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
+  }
+  const int64_t env = (blk * blockDim.x + threadIdx.x) * VEC;
   if (env >= N) return;
   float vnext[VEC], dn[VEC], tdn[VEC], last[VEC];
   load<VEC, ST>(next_val + env, vnext);
