@@ -46,7 +46,7 @@ __device__ __forceinline__ void store(ST* p, const float (&v)[VEC]) {
 //   1 rl_games  (rl_games/cat_common.py:96-103 -> A2CBase.discount_values with float fdones): the CleanRL
 //               recurrence without the time-out channel (tn == 1 exactly, one plane less to read)
 //   2 skrl      (skrl/ppo.py:397-442)        d = done_t:  A_t = (r_t - v_t) + (g*nd_t) * (v_{t+1} + l*A_{t+1})
-template <int VEC, int KIND, typename ST = float>
+template <int VEC, int KIND, typename ST = float, int UNR = 4>
 __global__ __launch_bounds__(256) void gae_scan(const ST* __restrict__ rew, const ST* __restrict__ val,
                                                 const ST* __restrict__ done, const ST* __restrict__ tdone,
                                                 const ST* __restrict__ next_val,
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gae_scan(const ST* __restrict__ rew, cons
 #pragma unroll
   for (int k = 0; k < VEC; ++k) last[k] = 0.0f;
 
-#pragma unroll 4
+#pragma unroll UNR
   for (int t = T - 1; t >= 0; --t) {
     const int64_t off = (int64_t)t * N + env;
     float r[VEC], v[VEC], d[VEC], td[VEC], a[VEC], q[VEC];
@@ -121,8 +121,15 @@ void launch_gae(bool wide, const ST* rewards, const ST* values, const ST* dones,
   constexpr int WV = 16 / (int)sizeof(ST);     // 16-B lanes: 4 fp32 / 8 fp16 envs
   if (wide) {
     const int block = 256;
-    gae_scan<WV, KIND, ST><<<dim3((unsigned)cdiv64(N / WV, block)), dim3(block), 0, s>>>(
-        rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma, gl, advantages, returns, T, N);
+    const dim3 grid((unsigned)cdiv64(N / WV, block));
+    // with >= 16 waves per CU in the grid, eight time steps of loads in flight per lane pay (4.8 GB fp32 sweep:
+    // 5.4 -> 6.1 TB/s); with fewer waves the longer dependent prologue costs more than it hides
+    if (N / WV >= (int64_t)256 * 64 * 16)
+      gae_scan<WV, KIND, ST, 8><<<grid, dim3(block), 0, s>>>(rewards, values, dones, true_dones, next_value, next_done,
+                                                             next_true_done, gamma, gl, advantages, returns, T, N);
+    else
+      gae_scan<WV, KIND, ST, 4><<<grid, dim3(block), 0, s>>>(rewards, values, dones, true_dones, next_value, next_done,
+                                                             next_true_done, gamma, gl, advantages, returns, T, N);
   } else {
     // small N: one wave per block so that 4096 envs already spread over 64 CUs
     const int block = N >= 65536 ? 256 : 64;
