@@ -338,7 +338,14 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
 #ifdef GEMM_PROBE_NOSTORE
           if (v == 12345.678f)
 #endif
-          if (inb) Cout[(int64_t)gi * p.ldc + gj] = v;
+          if (inb) {
+            float* dstp = Cout + (int64_t)gi * p.ldc + gj;
+            if constexpr (EPI == EPI_PARTIAL) {   // split-K partials: 16.8 MB per launch, re-read by the fold launch
+              asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(dstp), "v"(v) : "memory");
+            } else {
+              *dstp = v;
+            }
+          }
         }
       }
       if constexpr (STAGED) {
@@ -352,7 +359,17 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
 #ifdef GEMM_PROBE_NOSTORE
           if (q.x == 12345.678f)
 #endif
-          if (gi < p.I && gj4 + 3 < p.J) *reinterpret_cast<float4*>(Cout + (int64_t)gi * p.ldc + gj4) = q;
+          // write-through (non-temporal) row stores: tens of MB left dirty in L2 would be flushed at the kernel
+          // boundary (MI355X guide, "boundary": + bytes / 6 TB/s) - stream them out while the tile is still computing
+          if (gi < p.I && gj4 + 3 < p.J) {
+            using f4v = __attribute__((ext_vector_type(4))) float;
+            f4v o;
+            o.x = q.x, o.y = q.y, o.z = q.z, o.w = q.w;
+            float* dstp = Cout + (int64_t)gi * p.ldc + gj4;
+            // (the compiler's hazard recognizer does not see a store inside inline asm: a VALU write of the four data
+            // VGPRs right behind a >64-bit store needs a wait state, hence the s_nop)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dstp), "v"(o) : "memory");
+          }
         }
         __builtin_amdgcn_wave_barrier();
       }
