@@ -235,6 +235,29 @@ __device__ __forceinline__ void store_vec(float* p, const float (&v)[CPL]) {
   }
 }
 
+// the same store written through to memory (global stores only): activation-sized outputs that the NEXT launch
+// reads should not sit dirty in L2 until the kernel boundary flushes them (see gemm_f32.h epilogue)
+template <int CPL>
+__device__ __forceinline__ void store_vec_wt(float* p, const float (&v)[CPL]) {
+  using f4v = __attribute__((ext_vector_type(4))) float;
+  using f2v = __attribute__((ext_vector_type(2))) float;
+  if constexpr (CPL == 1) {
+    asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v[0]) : "memory");
+  } else if constexpr (CPL == 2) {
+    f2v o;
+    o.x = v[0], o.y = v[1];
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(o) : "memory");
+  } else {
+#pragma unroll
+    for (int q = 0; q < CPL / 4; ++q) {
+      f4v o;
+      o.x = v[4 * q], o.y = v[4 * q + 1], o.z = v[4 * q + 2], o.w = v[4 * q + 3];
+      float* dst = p + 4 * q;
+      asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dst), "v"(o) : "memory");
+    }
+  }
+}
+
 template <int CPL>
 __device__ __forceinline__ void load_vec(const float* p, float (&v)[CPL]) {
   if constexpr (CPL == 1) {
@@ -614,8 +637,8 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
         oa[c] = dha[c] * (ha[c] > 0.0f ? 1.0f : ha[c] + 1.0f);
         oc[c] = (g_v * wc[c]) * (hc[c] > 0.0f ? 1.0f : hc[c] + 1.0f);
       }
-      store_vec<CPL>(g.dZa + i * HL + lane * CPL, oa);
-      store_vec<CPL>(g.dZc + i * HL + lane * CPL, oc);
+      store_vec_wt<CPL>(g.dZa + i * HL + lane * CPL, oa);
+      store_vec_wt<CPL>(g.dZc + i * HL + lane * CPL, oc);
     }
     __syncthreads();
     // ------------------------------------------------------------------ phase 2: dW4 += G^T . H
