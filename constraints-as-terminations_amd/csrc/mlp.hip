@@ -6,7 +6,9 @@
 // log-prob / entropy, the clipped PPO losses AND their analytic gradients w.r.t. the last
 // hidden activations are one wave-per-row VALU kernel (head_loss): no autograd graph, no
 // (M,12) temporaries, no host sync.  Weight gradients are split-K over the batch with
-// deterministic two-stage reduction (no float atomics => run-to-run reproducible).
+// deterministic two-stage reduction (no float atomics => run-to-run reproducible); a layer's
+// weight-gradient and data-gradient GEMMs share one launch (gemm_pair_kernel), the minibatch is
+// gathered once per epoch (catppo_ppo_gather) and every partial is folded by one launch.
 #include "common.h"
 #include "gemm_f32.h"
 
@@ -1076,10 +1078,10 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     sg.src = src, sg.dst = dst, sg.count = count, sg.stride = stride, sg.n_parts = n_parts, sg.mode = mode,
     sg.scale = scale;
   };
-  // Backward: the data-gradient chain (dX GEMMs) stays on the caller's stream; each layer's weight
-  // gradient (split-K GEMM + fold of its partials) is forked to the side stream as soon as that
-  // layer's dZ exists, and everything is joined before returning to the caller's stream order.
-  // The split-K partial buffers are reused layer after layer; the side stream serialises them.
+  // Backward, default: per hidden layer ONE launch holding the split-K weight-gradient GEMM and the data-gradient
+  // GEMM (launch_dw_dx_pair), every layer with its own partial buffers, ONE fold launch at the end.
+  // CATPPO_SIDE_STREAM=1 (measured slower, kept for A/B): the weight gradients are forked to the context's side
+  // stream as soon as a layer's dZ exists and joined before returning to the caller's stream order.
   const bool fork = ctx->use_side;
   const bool bf16 = shape->mfma_bf16 != 0;
   hipStream_t side = fork ? ctx->side : s;
