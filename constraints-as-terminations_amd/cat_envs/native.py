@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcatppo.so")
 
 MAX_HIDDEN = 4
+TERM_MAX_IDS = 32     # CATPPO_TERM_MAX_IDS
 
 # catppo_term_kind
 TERM_ABS_LIMIT, TERM_ABS_DIFF_LIMIT, TERM_ABS_DIFF_LIMIT_GATE_CMDY, TERM_GREATER = 0, 1, 2, 3
@@ -42,12 +43,49 @@ class PpoHparams(C.Structure):
 
 
 class TermDesc(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("n_ids", C.c_int32), ("ids", C.c_int32 * 16),
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("n_ids", C.c_int32), ("ids", C.c_int32 * TERM_MAX_IDS),
                 ("limit", C.c_float), ("aux", C.c_float), ("x", C.c_void_p), ("y", C.c_void_p),
                 ("x_ld", C.c_int32), ("y_ld", C.c_int32)]
 
 
+class IterState(C.Structure):
+    """catppo_iter_state (device resident; this mirror is only used for its size and for read-backs in tests)"""
+    _fields_ = [("seed", C.c_uint64), ("iteration", C.c_int64), ("adam_step", C.c_int64), ("lr", C.c_double),
+                ("kl_mark", C.c_double), ("n_mark", C.c_double), ("last_kl", C.c_double), ("reserved", C.c_int64)]
+
+
+class RolloutStep(C.Structure):
+    """catppo_rollout_step: argument block of the fused rollout step (field order = include/catppo.h)"""
+    _fields_ = [
+        ("N", C.c_int64), ("A", C.c_int32), ("D", C.c_int32), ("K", C.c_int32), ("n_terms", C.c_int32),
+        ("action_in", C.c_void_p), ("action", C.c_void_p), ("prev_action", C.c_void_p),
+        ("episode_length", C.c_void_p), ("max_episode_length", C.c_int64),
+        ("hard_reset", C.c_void_p), ("hard_reset_stride", C.c_int64),
+        ("reward_src", C.c_void_p), ("reward_stride", C.c_int64),
+        ("time_outs", C.c_void_p), ("terminated", C.c_void_p), ("reset", C.c_void_p), ("reward", C.c_void_p),
+        ("desc", C.c_void_p), ("forces", C.c_void_p), ("forces_env_stride", C.c_int64), ("H", C.c_int32),
+        ("B", C.c_int32), ("command", C.c_void_p), ("command_ld", C.c_int32), ("cstr", C.c_void_p),
+        ("term_off", C.c_void_p), ("term_dp", C.c_void_p), ("min_p", C.c_float), ("tau", C.c_float),
+        ("one_minus_tau", C.c_float), ("first_call", C.c_int32),
+        ("rm", C.c_void_p), ("cstr_prob", C.c_void_p), ("dones", C.c_void_p), ("ep_viol", C.c_void_p),
+        ("ep_prob", C.c_void_p), ("probs", C.c_void_p),
+        ("log_prev", C.c_void_p), ("log_out", C.c_void_p), ("zero_action_on_reset", C.c_int32),
+        ("rewards_t", C.c_void_p), ("dones_t1", C.c_void_p), ("true_dones_t1", C.c_void_p),
+        ("plane_dtype", C.c_int32),
+        ("obs_raw", C.c_void_p), ("obs_ld", C.c_int64),
+        ("obs_mean", C.c_void_p), ("obs_var", C.c_void_p), ("obs_count", C.c_void_p), ("obs_eps", C.c_float),
+        ("obs_rows_total", C.c_double), ("obs_out", C.c_void_p), ("obs_out_ld", C.c_int64),
+        ("xchg", C.c_void_p)]
+
+
+F32, F16, F64 = 0, 1, 2                 # CATPPO_F32 / _F16 / _F64
+SUM, MAX = 0, 1                         # CATPPO_SUM / _MAX
+LR_FIXED, LR_LINEAR, LR_KEEP = 0, 1, 2
+GAE_SERIAL, GAE_SCAN = 0, 1
+UNIQUE_ID_BYTES = 128
+
 _vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+_u64 = C.c_uint64
 
 _SIGNATURES = {
     "catppo_version": (C.c_int, []),
@@ -95,6 +133,39 @@ _SIGNATURES = {
     "catppo_ppo_minibatch_grad_packed": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp,
                                                    _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catppo_clip_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _f64, _i64, _vp]),
+    # ---- ABI 0.2
+    "catppo_iter_init": (C.c_int, [_vp, _vp, _u64, _f64, _vp]),
+    "catppo_iter_begin": (C.c_int, [_vp, _vp, _f64, _i64, C.c_int, _vp]),
+    "catppo_clip_adam_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _vp, _vp]),
+    "catppo_kl_mean": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "catppo_kl_adaptive_lr": (C.c_int, [_vp, _vp, _vp, _f64, _f64, _f64, _f64, _f64, _vp]),
+    "catppo_policy_act_rng": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp,
+                                        C.c_int, _vp]),
+    "catppo_policy_act_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
+                                       _vp]),
+    "catppo_value_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, C.c_int, _vp]),
+    "catppo_ppo_gather_rng": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i32,
+                                        _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_rollout_store_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _i64, _vp]),
+    "catppo_rms_update_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "catppo_rms_normalize_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp, _f32, _vp, _i64, _vp]),
+    "catppo_gae_mode": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
+                                  _vp]),
+    "catppo_rollout_xchg_bytes": (C.c_uint64, [C.c_int, C.c_int]),
+    "catppo_rollout_xchg_sum_offset": (C.c_uint64, [C.c_int]),
+    "catppo_rollout_step_sizeof": (C.c_uint64, []),
+    "catppo_rollout_pre": (C.c_int, [_vp, C.POINTER(RolloutStep), _vp]),
+    "catppo_rollout_post": (C.c_int, [_vp, C.POINTER(RolloutStep), _vp]),
+    "catppo_graph_begin": (C.c_int, [_vp, _vp]),
+    "catppo_graph_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "catppo_graph_launch": (C.c_int, [_vp, C.c_int, _vp]),
+    "catppo_graph_destroy": (C.c_int, [_vp, C.c_int]),
+    "catppo_comm_unique_id": (C.c_int, [_vp]),
+    "catppo_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "catppo_comm_world": (C.c_int, [_vp]),
+    "catppo_comm_destroy": (C.c_int, [_vp]),
+    "catppo_allreduce": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
+    "catppo_broadcast": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -134,6 +205,9 @@ def load_library(path: Optional[str] = None):
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
+    if lib.catppo_rollout_step_sizeof() != C.sizeof(RolloutStep):
+        raise RuntimeError(f"catppo_rollout_step layout mismatch: library {lib.catppo_rollout_step_sizeof()} B, "
+                           f"binding {C.sizeof(RolloutStep)} B (rebuild libcatppo.so)")
     _lib = lib
     return lib
 
@@ -422,3 +496,144 @@ class Native:
         self._ok(self.lib.catppo_clip_adam(self.h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), int(n_flat),
                                            f32(max_grad_norm), float(lr), float(beta1), float(beta2), float(eps),
                                            int(step), self._stream()))
+
+    # ------------------------------------------------------------------ ABI 0.2: device iteration state
+    def iter_state_new(self, seed: int, lr: float) -> torch.Tensor:
+        """device-resident catppo_iter_state as a uint8 tensor (the library's kernels own its contents)"""
+        st = torch.zeros(C.sizeof(IterState), dtype=torch.uint8, device=self.device)
+        self._ok(self.lib.catppo_iter_init(self.h, _p(st), int(seed) & (2 ** 64 - 1), float(lr), self._stream()))
+        return st
+
+    def iter_state_read(self, st: torch.Tensor) -> IterState:
+        """host copy (synchronises; tests / logging only)"""
+        return IterState.from_buffer_copy(bytes(st.cpu().numpy().tobytes()))
+
+    def iter_begin(self, st, lr0, num_iterations, schedule):
+        self._ok(self.lib.catppo_iter_begin(self.h, _p(st), float(lr0), int(num_iterations), int(schedule),
+                                            self._stream()))
+
+    def clip_adam_dev(self, params, grad, exp_avg, exp_avg_sq, n_flat, max_grad_norm, beta1, beta2, eps, st):
+        self._ok(self.lib.catppo_clip_adam_dev(self.h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), int(n_flat),
+                                               f32(max_grad_norm), float(beta1), float(beta2), float(eps), _p(st),
+                                               self._stream()))
+
+    def kl_mean(self, st, diag, kl_out):
+        self._ok(self.lib.catppo_kl_mean(self.h, _p(st), _p(diag), _p(kl_out), self._stream()))
+
+    def kl_adaptive_lr(self, st, kl, kl_threshold, kl_factor=2.0, lr_factor=1.5, min_lr=1e-6, max_lr=1e-2):
+        self._ok(self.lib.catppo_kl_adaptive_lr(self.h, _p(st), _p(kl), float(kl_threshold), float(kl_factor),
+                                                float(lr_factor), float(min_lr), float(max_lr), self._stream()))
+
+    # ------------------------------------------------------------------ on-device randomness / fp16 planes
+    @staticmethod
+    def _dt(t: torch.Tensor) -> int:
+        if t.dtype == torch.float32:
+            return F32
+        if t.dtype == torch.float16:
+            return F16
+        if t.dtype == torch.float64:
+            return F64
+        raise TypeError(f"unsupported element type {t.dtype}")
+
+    def policy_act_rng(self, shape, params, x, n_rows, st, step, action, logprob, value, eps_out=None):
+        self._ok(self.lib.catppo_policy_act_rng(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(st),
+                                                int(step), _p(eps_out), _p(action), _p(logprob), _p(value),
+                                                self._dt(value), self._stream()))
+
+    def policy_act_ex(self, shape, params, x, n_rows, eps, action, logprob, value, given_action=None):
+        self._ok(self.lib.catppo_policy_act_ex(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
+                                               _p(given_action), _p(action), _p(logprob), _p(value), self._dt(value),
+                                               self._stream()))
+
+    def value_ex(self, shape, params, x, n_rows, value):
+        self._ok(self.lib.catppo_value_ex(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(value),
+                                          self._dt(value), self._stream()))
+
+    def ppo_gather_rng(self, shape, b_obs, b_actions, b_logprobs, b_advantages, b_returns_n, b_values_n, st, epoch,
+                       total, M, x_g, act_g, scal_g, adv_part_g, inds_out=None):
+        self._ok(self.lib.catppo_ppo_gather_rng(
+            self.h, C.byref(shape), _p(b_obs), _p(b_actions), _p(b_logprobs), _p(b_advantages),
+            self._dt(b_advantages), _p(b_returns_n), _p(b_values_n), _p(st), int(epoch), int(total), int(M), _p(x_g),
+            _p(act_g), _p(scal_g), _p(adv_part_g), _p(inds_out), self._stream()))
+
+    def rollout_store_ex(self, reward, dones, time_outs, rewards_t, dones_t1, true_dones_t1):
+        self._ok(self.lib.catppo_rollout_store_ex(self.h, _p(reward), _p(dones), _p(time_outs), _p(rewards_t),
+                                                  _p(dones_t1), _p(true_dones_t1), self._dt(rewards_t), reward.numel(),
+                                                  self._stream()))
+
+    def rms_update_ex(self, x, n_rows, dim, ldx, mean, var, count):
+        self._ok(self.lib.catppo_rms_update_ex(self.h, _p(x), self._dt(x), int(n_rows), int(dim), int(ldx), _p(mean),
+                                               _p(var), _p(count), self._stream()))
+
+    def rms_normalize_ex(self, x, n_rows, dim, ldx, mean, var, eps, out, ldo):
+        self._ok(self.lib.catppo_rms_normalize_ex(self.h, _p(x), self._dt(x), int(n_rows), int(dim), int(ldx),
+                                                  _p(mean), _p(var), f32(eps), _p(out), int(ldo), self._stream()))
+
+    def gae_mode(self, mode, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma,
+                 gae_lambda, advantages, returns):
+        T, N = rewards.shape
+        for n, t in (("rewards", rewards), ("values", values), ("dones", dones), ("true_dones", true_dones),
+                     ("next_value", next_value), ("next_done", next_done), ("next_true_done", next_true_done),
+                     ("advantages", advantages), ("returns", returns)):
+            _chk(t, torch.float32, n)
+        self._ok(self.lib.catppo_gae_mode(self.h, int(mode), _p(rewards), _p(values), _p(dones), _p(true_dones),
+                                          _p(next_value), _p(next_done), _p(next_true_done), f32(gamma),
+                                          f32(gamma * gae_lambda), _p(advantages), _p(returns), T, N, self._stream()))
+
+    # ------------------------------------------------------------------ fused rollout step
+    def rollout_xchg_new(self, K: int, D: int) -> torch.Tensor:
+        return torch.zeros(int(self.lib.catppo_rollout_xchg_bytes(int(K), int(D))), dtype=torch.uint8,
+                           device=self.device)
+
+    def rollout_xchg_views(self, xchg: torch.Tensor, K: int, D: int):
+        """(colmax fp32 [K], sums fp64 [2D]) views of the exchange buffer (the all-reduce operands when sharded)"""
+        off = int(self.lib.catppo_rollout_xchg_sum_offset(int(K)))
+        return xchg[:4 * K].view(torch.float32), xchg[off:off + 16 * max(D, 1)].view(torch.float64)
+
+    def rollout_pre(self, step: RolloutStep):
+        self._ok(self.lib.catppo_rollout_pre(self.h, C.byref(step), self._stream()))
+
+    def rollout_post(self, step: RolloutStep):
+        self._ok(self.lib.catppo_rollout_post(self.h, C.byref(step), self._stream()))
+
+    # ------------------------------------------------------------------ hipGraphs
+    def graph_begin(self):
+        self._ok(self.lib.catppo_graph_begin(self.h, self._stream()))
+
+    def graph_end(self):
+        gid, nn = C.c_int(-1), C.c_int(0)
+        self._ok(self.lib.catppo_graph_end(self.h, self._stream(), C.byref(gid), C.byref(nn)))
+        return gid.value, nn.value
+
+    def graph_launch(self, gid: int):
+        self._ok(self.lib.catppo_graph_launch(self.h, int(gid), self._stream()))
+
+    def graph_destroy(self, gid: int):
+        self._ok(self.lib.catppo_graph_destroy(self.h, int(gid)))
+
+    # ------------------------------------------------------------------ collectives (RCCL under the C ABI)
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        rc = self.lib.catppo_comm_unique_id(C.cast(buf, _vp))
+        if rc != 0:
+            raise RuntimeError(f"catppo_comm_unique_id failed ({rc}): librccl could not be loaded")
+        return bytes(buf)
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        self._ok(self.lib.catppo_comm_init(self.h, int(rank), int(world), C.cast(buf, _vp)))
+
+    @property
+    def comm_world(self) -> int:
+        return int(self.lib.catppo_comm_world(self.h))
+
+    def comm_destroy(self):
+        self._ok(self.lib.catppo_comm_destroy(self.h))
+
+    def allreduce(self, t: torch.Tensor, op: int = SUM):
+        self._ok(self.lib.catppo_allreduce(self.h, _p(_chk(t, t.dtype, "allreduce operand")), t.numel(), self._dt(t),
+                                           int(op), self._stream()))
+
+    def broadcast(self, t: torch.Tensor, root: int = 0):
+        self._ok(self.lib.catppo_broadcast(self.h, _p(_chk(t, t.dtype, "broadcast operand")), t.numel(), self._dt(t),
+                                           int(root), self._stream()))

@@ -66,6 +66,14 @@ class SixConstraintsCfg:
     base_orientation = ConstraintsCfg.__dataclass_fields__["base_orientation"].default_factory()
 
 
+@configclass
+class TwoConstraintsCfg:
+    """BASELINE.json config 1 (plumbing case): two terms, 13 columns - one soft (C3 joint_torque), one hard
+    boolean (C7 contact)."""
+    joint_torque = ConstraintsCfg.__dataclass_fields__["joint_torque"].default_factory()
+    contact = ConstraintsCfg.__dataclass_fields__["contact"].default_factory()
+
+
 MAX_CURRICULUM_ITERATIONS = 1000
 
 
@@ -94,6 +102,11 @@ class SixCurriculumCfg:
     joint_velocity = _anneal("joint_velocity")
     action_rate = _anneal("action_rate")
     base_orientation = _anneal("base_orientation")
+
+
+@configclass
+class TwoCurriculumCfg:
+    joint_torque = _anneal("joint_torque")
 
 
 @configclass

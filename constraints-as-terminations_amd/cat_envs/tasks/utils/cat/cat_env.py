@@ -144,6 +144,18 @@ class _ActionManager:
         self._action.copy_(action)
 
     def reset(self, env_ids=None):
+        """IsaacLab's ActionManager.reset: the action history of the envs that reset starts from zero, so the
+        action-rate constraint of their first step sees ``|a - 0| / dt`` (mask, index list or None = all)."""
+        if env_ids is None or isinstance(env_ids, slice):
+            self._action.zero_()
+            self._prev_action.zero_()
+        elif isinstance(env_ids, torch.Tensor) and env_ids.dtype == torch.bool:
+            keep = (~env_ids).unsqueeze(1)
+            self._action.mul_(keep)
+            self._prev_action.mul_(keep)
+        else:
+            self._action[env_ids] = 0.0
+            self._prev_action[env_ids] = 0.0
         return {}
 
 

@@ -157,6 +157,7 @@ class ConstraintManager(ManagerBase):
         self._bound = False
         self._fused = False
         self._desc_cache = None
+        self._desc_key = None
         self.term_cache = True
         self._widths: List[int] = []
         self._term_off = None
@@ -235,6 +236,15 @@ class ConstraintManager(ManagerBase):
             term_cfg.func.reset(env_ids=env_ids)
         return extras
 
+    def ensure_log_ring(self, n_slots: int):
+        """make reset() results stay valid for at least ``n_slots`` further resets (a trainer that reads the
+        per-step logs after a rollout of T steps needs T + 1)"""
+        if n_slots <= self.LOG_RING:
+            return
+        ring = torch.zeros(n_slots, self._log_ring.shape[1], device=self._device)
+        ring[:self.LOG_RING] = self._log_ring
+        self.LOG_RING, self._log_ring, self._log_views = n_slots, ring, None
+
     @property
     def log_packed(self):
         """(keys, tensor[2*n_terms]) of the latest reset() - lets a trainer stack one tensor per
@@ -249,9 +259,13 @@ class ConstraintManager(ManagerBase):
         """first compute(): learn every term's width, allocate the packed buffers"""
         env = self._env
         descs = []
+        from .constraints import TooManyIds
         for cfg in self._term_cfgs:
             d = getattr(cfg.func, "describe", None)
-            descs.append(d(env, **cfg.params) if d is not None else None)
+            try:
+                descs.append(d(env, **cfg.params) if d is not None else None)
+            except TooManyIds:                     # wider than the descriptor's id table: per-term path
+                descs.append(None)
         self._fused = all(d is not None for d in descs) and len(descs) <= 16
         if self._fused:
             widths = [d.width for d in descs]
@@ -274,10 +288,15 @@ class ConstraintManager(ManagerBase):
         updated in place) plus the term parameters, which only change through ``set_term_cfg`` (that drops
         the cache).  Tables with a converted (copied) input are never cached; ``self.term_cache = False``
         re-describes every step regardless."""
-        cache = self._desc_cache if self.term_cache else None
-        if cache is not None:
-            return cache
         env = self._env
+        # Raw device pointers may only be kept across steps when the env guarantees that its ``data.*`` tensors
+        # are allocated once and updated in place (``persistent_state_buffers``).  Any other env (IsaacLab lazy
+        # buffers, a simulator that rebinds tensors) is re-described every step, like the reference, which
+        # re-evaluates the term inputs on every compute().
+        persistent = bool(getattr(env, "persistent_state_buffers", False))
+        cache = self._desc_cache if (self.term_cache and persistent) else None
+        if cache is not None and self._desc_key == self._params_key():
+            return cache
         rows, forces, command, H, B, keep = [], None, None, 1, 1, []
         for cfg in self._term_cfgs:
             d = cfg.func.describe(env, **cfg.params)
@@ -292,8 +311,26 @@ class ConstraintManager(ManagerBase):
         table = (arr, forces, H, B, command)
         # cache only tables whose pointers aim at the simulator's own buffers: a term input that needed a dtype /
         # layout conversion was COPIED by describe(), and a cached pointer to that copy would go stale
-        self._desc_cache = table if all(d.cacheable for d in keep) else None
+        self._desc_cache = table if (persistent and all(d.cacheable for d in keep)) else None
+        self._desc_key = self._params_key()
         return table
+
+    def _params_key(self):
+        """cheap snapshot of everything a descriptor row is built from: the term functions and their parameters
+        (scalars by value, SceneEntityCfg by its resolved ids).  In-place edits of ``term_cfg.params`` - with or
+        without a ``set_term_cfg`` call - change the key and rebuild the table; ``max_p`` is not part of it (it
+        travels with every launch)."""
+        key = []
+        for cfg in self._term_cfgs:
+            row = [id(cfg.func)]
+            for k, v in cfg.params.items():
+                if isinstance(v, (int, float, str, bool)) or v is None:
+                    row.append((k, v))
+                else:
+                    ids = (getattr(v, "joint_ids", None), getattr(v, "body_ids", None))
+                    row.append((k, id(v), tuple(str(i) for i in ids)))
+            key.append(tuple(row))
+        return tuple(key)
 
     def compute(self, reward: torch.Tensor | None = None, reset_mask: torch.Tensor | None = None,
                 dones: torch.Tensor | None = None) -> torch.Tensor:
@@ -355,9 +392,9 @@ class ConstraintManager(ManagerBase):
         i = self._term_names.index(term_name)
         old = self._term_cfgs[i]
         self._term_cfgs[i] = cfg
-        # the curriculum rewrites max_p through here at every reset; only a different function / parameter set
-        # changes the descriptor table of the fused term kernel
-        if cfg.func is not old.func or cfg.params is not old.params and cfg.params != old.params:
+        # the curriculum rewrites max_p through here at every reset (max_p travels with every launch); a changed
+        # function / parameter set is caught by the parameter snapshot checked in _describe_terms()
+        if cfg.func is not old.func:
             self._desc_cache = None
 
     def get_term_cfg(self, term_name: str) -> ConstraintTermCfg:

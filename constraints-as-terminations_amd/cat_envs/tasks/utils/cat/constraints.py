@@ -19,6 +19,14 @@ from cat_envs.native import (TERM_ABS_DIFF_LIMIT, TERM_ABS_DIFF_LIMIT_GATE_CMDY,
 from cat_envs.shim import SceneEntityCfg
 
 
+MAX_TERM_IDS = native.TERM_MAX_IDS      # catppo_term_desc.ids
+
+
+class TooManyIds(ValueError):
+    """a selection wider than the descriptor's id table (32 ids; Solo12 has 12 joints / 17 bodies).  The manager
+    then leaves the fused table and evaluates the config term by term; per-id terms are evaluated in chunks."""
+
+
 class TermDescription:
     """one descriptor row + the tensors it points to (kept alive while the row is in use).
 
@@ -28,6 +36,8 @@ class TermDescription:
 
     def __init__(self, kind, width, ids, limit=0.0, aux=0.0, x=None, y=None, forces=None, command=None,
                  is_bool=False):
+        if len(ids) > MAX_TERM_IDS:
+            raise TooManyIds(f"term selects {len(ids)} joints/bodies; the fused term kernel takes {MAX_TERM_IDS}")
         d = TermDesc()
         d.kind, d.width, d.n_ids = kind, width, len(ids)
         for i, v in enumerate(ids):

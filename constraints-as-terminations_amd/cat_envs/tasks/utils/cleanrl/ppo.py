@@ -289,6 +289,9 @@ class PPOTrainer:
             cm = getattr(envs.unwrapped, "constraint_manager", None)
             if cm is not None and getattr(c, "dist_exact", True):
                 cm.dist_group = torch.distributed.group.WORLD
+        cm = getattr(envs.unwrapped, "constraint_manager", None)
+        if cm is not None and hasattr(cm, "ensure_log_ring"):
+            cm.ensure_log_ring(self.T + 2)      # the per-step episode logs are read after the rollout
         n_flat = a.layout.n_flat
         dev, T, N = self.device, self.T, self.N
         z = lambda *s, **k: torch.zeros(*s, device=dev, **k)
@@ -345,7 +348,12 @@ class PPOTrainer:
             if "episode" in info:
                 ep_infos.append(info["episode"])
             elif "log" in info:
-                ep_infos.append(info.get("log_packed", info["log"]))
+                packed = info.get("log_packed")
+                if packed is None:
+                    ep_infos.append(info["log"])
+                else:                                 # (keys, device tensor) + the host-side scalars of the log
+                    extra = {k: v for k, v in info["log"].items() if not isinstance(v, torch.Tensor)}
+                    ep_infos.append((packed[0], packed[1], extra))
             info["true_dones"] = timeouts
             a.obs_rms.normalize_into(self._rows(next_obs["policy"]), self.obs[step + 1])
             if "time_outs" in info:
@@ -455,10 +463,13 @@ class PPOTrainer:
         if not ep_infos:
             return
         first = ep_infos[0]
-        if isinstance(first, tuple):                             # packed (keys, tensor) from CaTEnv
+        if isinstance(first, tuple):                             # packed (keys, tensor, host scalars) from CaTEnv
             keys = first[0]
-            vals = torch.stack([t for _, t in ep_infos]).mean(0).cpu().numpy()
-            items = zip(keys, vals)
+            vals = torch.stack([e[1] for e in ep_infos]).mean(0).cpu().numpy()
+            items = list(zip(keys, vals))
+            for key in first[2]:                                 # e.g. "Curriculum/<term>" (reference logs them too)
+                vs = [float(e[2][key]) for e in ep_infos if key in e[2]]
+                items.append((key, sum(vs) / len(vs)))
         else:
             items = []
             for key in first:

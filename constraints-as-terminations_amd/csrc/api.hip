@@ -27,6 +27,8 @@ extern "C" int catppo_create(int device, catppo_ctx** out) {
   bool ok = hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess;
   for (auto& e : ctx->ev_fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipMalloc(reinterpret_cast<void**>(&ctx->tickets), sizeof(unsigned int) * catppo_ctx::kTickets) == hipSuccess;
+  ok = ok && hipMemset(ctx->tickets, 0, sizeof(unsigned int) * catppo_ctx::kTickets) == hipSuccess;
   (void)hipSetDevice(cur);
   if (!ok) {
     delete ctx;
@@ -47,6 +49,10 @@ extern "C" void catppo_destroy(catppo_ctx* ctx) {
   int cur = 0;
   (void)hipGetDevice(&cur);
   (void)hipSetDevice(ctx->device);
+  (void)catppo_comm_destroy(ctx);
+  for (auto& g : ctx->graphs)
+    if (g) (void)hipGraphExecDestroy(g);
+  if (ctx->tickets) (void)hipFree(ctx->tickets);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& e : ctx->ev_fork)
@@ -61,6 +67,9 @@ extern "C" const char* catppo_last_error(catppo_ctx* ctx) { return ctx ? ctx->er
 extern "C" int catppo_reserve(catppo_ctx* ctx, uint64_t bytes) {
   if (!ctx) return CATPPO_E_ARG;
   if (bytes <= ctx->ws_bytes) return CATPPO_OK;
+  if (ctx->capturing)
+    return catppo_fail(ctx, CATPPO_E_ARG, "catppo_reserve: cannot grow the workspace while a graph capture is active "
+                                          "(reserve %llu B before catppo_graph_begin)", (unsigned long long)bytes);
   int cur = 0;
   (void)hipGetDevice(&cur);
   (void)hipSetDevice(ctx->device);
@@ -77,5 +86,66 @@ extern "C" int catppo_reserve(catppo_ctx* ctx, uint64_t bytes) {
   ctx->ws = p;
   ctx->ws_bytes = bytes;
   (void)hipSetDevice(cur);
+  return CATPPO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- hipGraphs
+extern "C" int catppo_graph_begin(catppo_ctx* ctx, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, stream != nullptr);      // the legacy default stream cannot be captured
+  CATPPO_CHECK_ARG(ctx, !ctx->capturing);
+  // relaxed mode: host threads of the process (allocator, data loaders) may keep calling the runtime
+  hipError_t e = hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess)
+    return catppo_fail(ctx, CATPPO_E_HIP, "catppo_graph_begin: hipStreamBeginCapture: %s", hipGetErrorString(e));
+  ctx->capturing = true;
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, int* n_nodes) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, ctx->capturing && graph_id != nullptr);
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(static_cast<hipStream_t>(stream), &g);
+  if (e != hipSuccess || g == nullptr)
+    return catppo_fail(ctx, CATPPO_E_HIP, "catppo_graph_end: hipStreamEndCapture: %s", hipGetErrorString(e));
+  size_t nn = 0;
+  (void)hipGraphGetNodes(g, nullptr, &nn);
+  if (n_nodes) *n_nodes = (int)nn;
+  int slot = -1;
+  for (int i = 0; i < catppo_ctx::kMaxGraphs; ++i)
+    if (ctx->graphs[i] == nullptr) {
+      slot = i;
+      break;
+    }
+  if (slot < 0) {
+    (void)hipGraphDestroy(g);
+    return catppo_fail(ctx, CATPPO_E_ARG, "catppo_graph_end: all %d graph slots are in use", catppo_ctx::kMaxGraphs);
+  }
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (e != hipSuccess)
+    return catppo_fail(ctx, CATPPO_E_HIP, "catppo_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+  ctx->graphs[slot] = ex;
+  *graph_id = slot;
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_graph_launch(catppo_ctx* ctx, int graph_id, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, graph_id >= 0 && graph_id < catppo_ctx::kMaxGraphs && ctx->graphs[graph_id] != nullptr);
+  hipError_t e = hipGraphLaunch(ctx->graphs[graph_id], static_cast<hipStream_t>(stream));
+  if (e != hipSuccess)
+    return catppo_fail(ctx, CATPPO_E_HIP, "catppo_graph_launch: %s", hipGetErrorString(e));
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_graph_destroy(catppo_ctx* ctx, int graph_id) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, graph_id >= 0 && graph_id < catppo_ctx::kMaxGraphs);
+  if (ctx->graphs[graph_id]) (void)hipGraphExecDestroy(ctx->graphs[graph_id]);
+  ctx->graphs[graph_id] = nullptr;
   return CATPPO_OK;
 }

@@ -21,6 +21,16 @@ struct catppo_ctx {
   bool use_side = false;     // CATPPO_SIDE_STREAM=1 forks the weight-gradient GEMMs (measured slower)
   hipEvent_t ev_fork[CATPPO_MAX_HIDDEN + 1] = {};
   hipEvent_t ev_join = nullptr;
+  // hipGraphs captured through catppo_graph_begin / _end (index = graph id; destroyed slots are null)
+  static constexpr int kMaxGraphs = 64;
+  hipGraphExec_t graphs[kMaxGraphs] = {};
+  bool capturing = false;
+  // RCCL communicator (comm.hip; librccl is dlopen'ed on first use)
+  void* comm = nullptr;      // ncclComm_t
+  int comm_rank = 0, comm_world = 0;
+  // device-side completion tickets of the "last workgroup folds" kernels (zero between launches)
+  unsigned int* tickets = nullptr;   // [kTickets]
+  static constexpr int kTickets = 16;
   char err[512] = {0};
 };
 

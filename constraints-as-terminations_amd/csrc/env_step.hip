@@ -35,14 +35,15 @@ __global__ __launch_bounds__(256) void env_pre_step_kernel(const float* __restri
   }
 }
 
+template <typename ST>
 __global__ __launch_bounds__(256) void rollout_store_kernel(const float* __restrict__ reward, const float* __restrict__ dones,
                                                             const uint8_t* __restrict__ time_outs,
-                                                            float* __restrict__ rewards_t, float* __restrict__ dones_t1,
-                                                            float* __restrict__ true_dones_t1, int64_t N) {
+                                                            ST* __restrict__ rewards_t, ST* __restrict__ dones_t1,
+                                                            ST* __restrict__ true_dones_t1, int64_t N) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
-    rewards_t[i] = reward[i];
-    dones_t1[i] = dones[i];
-    true_dones_t1[i] = time_outs[i] ? 1.0f : 0.0f;
+    rewards_t[i] = (ST)reward[i];          // fp16 planes: round to nearest even
+    dones_t1[i] = (ST)dones[i];
+    true_dones_t1[i] = time_outs[i] ? (ST)1.0f : (ST)0.0f;
   }
 }
 
@@ -71,8 +72,27 @@ extern "C" int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const 
   CATPPO_CHECK_ARG(ctx, reward && dones && time_outs && rewards_t && dones_t1 && true_dones_t1 && N >= 1);
   int64_t nblk = cdiv64(N, 256);
   if (nblk > 1024) nblk = 1024;
-  hipLaunchKernelGGL(rollout_store_kernel, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream), reward,
-                     dones, time_outs, rewards_t, dones_t1, true_dones_t1, N);
+  hipLaunchKernelGGL(rollout_store_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reward, dones, time_outs, rewards_t, dones_t1, true_dones_t1, N);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_rollout_store_ex(catppo_ctx* ctx, const float* reward, const float* dones,
+                                       const uint8_t* time_outs, void* rewards_t, void* dones_t1, void* true_dones_t1,
+                                       int dtype, int64_t N, void* stream) {
+  if (dtype == CATPPO_F32)
+    return catppo_rollout_store(ctx, reward, dones, time_outs, static_cast<float*>(rewards_t),
+                                static_cast<float*>(dones_t1), static_cast<float*>(true_dones_t1), N, stream);
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, reward && dones && time_outs && rewards_t && dones_t1 && true_dones_t1 && N >= 1);
+  int64_t nblk = cdiv64(N, 256);
+  if (nblk > 1024) nblk = 1024;
+  using h = _Float16;
+  hipLaunchKernelGGL(rollout_store_kernel<h>, dim3((unsigned)nblk), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reward, dones, time_outs, static_cast<h*>(rewards_t), static_cast<h*>(dones_t1),
+                     static_cast<h*>(true_dones_t1), N);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

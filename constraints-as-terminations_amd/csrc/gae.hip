@@ -174,7 +174,133 @@ int gae_any(catppo_ctx* ctx, int kind, const ST* rewards, const ST* values, cons
   return CATPPO_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Scan mode (small N): the time axis of one env is split over G = 2^k lanes of a wavefront.
+//   lane (g, e): env e of the wave's E = 64/G envs, time chunk g = steps [g*CH, (g+1)*CH)
+//   1. the lane loads its chunk (independent of every other lane) and composes, from the chunk's last step
+//      backwards, the affine map  A_in -> A_out = Dm + Cm * A_in   of the recurrence A_t = delta_t + c_t * A_{t+1}
+//   2. inclusive suffix scan of the maps over g with wavefront shuffles (log2 G steps, lanes g*E+e and (g+s)*E+e):
+//      afterwards Dm is A at the first step of the lane's chunk given A_T = 0
+//   3. the value entering the chunk is the scanned Dm of lane g+1 (one more shuffle); replay the chunk serially
+//      from it and store advantages / returns.
+// For a fixed g the E lanes read E consecutive envs of one (T,N) row, so a wave touches G row segments of 4E bytes
+// per load - the planes were written by the rollout a moment ago and sit in L2 / Infinity Cache at these sizes.
+// 4096 envs x 24 steps: 512 wavefronts instead of 64, per-lane dependent chain 3 steps + 3 shuffles instead of 24.
+template <int G, int CHMAX>
+__global__ __launch_bounds__(256) void gae_scan_lanes(const float* __restrict__ rew, const float* __restrict__ val,
+                                                      const float* __restrict__ done, const float* __restrict__ tdone,
+                                                      const float* __restrict__ next_val,
+                                                      const float* __restrict__ next_done,
+                                                      const float* __restrict__ next_tdone, float gamma, float gl,
+                                                      float* __restrict__ adv, float* __restrict__ ret, int T,
+                                                      int64_t N, int CH) {
+  constexpr int E = 64 / G;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / E, e = lane - g * E;
+  const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t env = wave * E + e;
+  const bool live = env < N;
+  const int t0 = g * CH, t1 = (t0 + CH) < T ? (t0 + CH) : T;     // [t0, t1); empty when t0 >= T
+  float dl[CHMAX], cc[CHMAX], vv[CHMAX];
+  float Dm = 0.0f, Cm = 1.0f;                                      // identity map for empty chunks / dead lanes
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < CHMAX; ++k) {
+      const int t = t0 + k;
+      if (k < CH && t < T) {
+        const int64_t off = (int64_t)t * N + env;
+        const bool lastrow = t == T - 1;
+        const float r = rew[off], v = val[off];
+        const float nv = lastrow ? next_val[env] : val[off + N];
+        const float nd = lastrow ? next_done[env] : done[off + N];
+        const float ntd = lastrow ? next_tdone[env] : tdone[off + N];
+        const float nn = 1.0f - nd, tn = 1.0f - ntd;
+        float x = gamma * nv;
+        x = x * nn;
+        x = x * tn;
+        float c = gl * nn;
+        c = c * tn;
+        float d = r + x;
+        d = d - v;
+        dl[k] = d, cc[k] = c, vv[k] = v;
+      } else {
+        dl[k] = 0.0f, cc[k] = 1.0f, vv[k] = 0.0f;
+      }
+    }
+    // compose from the chunk's last step backwards: A_{t} = dl + cc * A_{t+1}
+#pragma unroll
+    for (int k = CHMAX - 1; k >= 0; --k) {
+      Dm = dl[k] + cc[k] * Dm;
+      Cm = cc[k] * Cm;
+    }
+  }
+  // inclusive suffix scan over g: (D,C)_g <- (D,C)_g o (D,C)_{g+s}
+#pragma unroll
+  for (int s = 1; s < G; s <<= 1) {
+    const float D2 = __shfl_down(Dm, s * E, 64), C2 = __shfl_down(Cm, s * E, 64);
+    if (g + s < G) {
+      Dm = Dm + Cm * D2;
+      Cm = Cm * C2;
+    }
+  }
+  float a_in = __shfl_down(Dm, E, 64);       // A at the first step of chunk g+1
+  if (g == G - 1) a_in = 0.0f;
+  if (!live) return;
+#pragma unroll
+  for (int k = CHMAX - 1; k >= 0; --k) {
+    const int t = t0 + k;
+    if (k < CH && t < t1) {
+      a_in = dl[k] + cc[k] * a_in;
+      const int64_t off = (int64_t)t * N + env;
+      adv[off] = a_in;
+      ret[off] = a_in + vv[k];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int catppo_gae_mode(catppo_ctx* ctx, int mode, const float* rewards, const float* values,
+                               const float* dones, const float* true_dones, const float* next_value,
+                               const float* next_done, const float* next_true_done, float gamma, float gamma_lambda,
+                               float* advantages, float* returns, int T, int64_t N, void* stream) {
+  if (mode == CATPPO_GAE_SERIAL)
+    return catppo_gae_ex(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
+                         next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, mode == CATPPO_GAE_SCAN);
+  CATPPO_CHECK_ARG(ctx, rewards && values && dones && true_dones && next_value && next_done && next_true_done &&
+                            advantages && returns && T >= 1 && N >= 1);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // lanes per env: as many as keep >= 2 steps per lane, at most 16; chunk length CH = ceil(T / G) <= 8
+  int G = 8;                                      // 8 lanes x 8 envs per wave: 32-B row segments
+  if ((T + G - 1) / G > 4) G = 16;                // long horizons: more lanes per env, chunks of <= 8 steps
+  while (G > 1 && (T + G - 1) / G < 2) G >>= 1;
+  int CH = (T + G - 1) / G;
+  if (CH > 8) {    // long horizons: the serial kernel already has T-deep independent loads per lane
+    return catppo_gae_ex(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
+                         next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
+  }
+  const int E = 64 / G;
+  const int64_t waves = cdiv64(N, E);
+  const int wpb = 4;
+  const dim3 grid((unsigned)cdiv64(waves, wpb)), block(64 * wpb);
+#define CATPPO_GAE_SCAN_LAUNCH(GG, CM)                                                                              \
+  hipLaunchKernelGGL((gae_scan_lanes<GG, CM>), grid, block, 0, s, rewards, values, dones, true_dones, next_value,   \
+                     next_done, next_true_done, gamma, gamma_lambda, advantages, returns, T, N, CH)
+  const int CM = CH <= 2 ? 2 : (CH <= 4 ? 4 : 8);
+  if (G == 16 && CM == 2) CATPPO_GAE_SCAN_LAUNCH(16, 2);
+  else if (G == 16 && CM == 4) CATPPO_GAE_SCAN_LAUNCH(16, 4);
+  else if (G == 16) CATPPO_GAE_SCAN_LAUNCH(16, 8);
+  else if (G == 8 && CM == 2) CATPPO_GAE_SCAN_LAUNCH(8, 2);
+  else if (G == 8) CATPPO_GAE_SCAN_LAUNCH(8, 4);
+  else if (G == 4) CATPPO_GAE_SCAN_LAUNCH(4, 2);
+  else if (G == 2) CATPPO_GAE_SCAN_LAUNCH(2, 2);
+  else CATPPO_GAE_SCAN_LAUNCH(1, 2);
+#undef CATPPO_GAE_SCAN_LAUNCH
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
 
 extern "C" int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values,
                              const float* dones, const float* true_dones, const float* next_value,

@@ -11,6 +11,7 @@
 // gathered once per epoch (catppo_ppo_gather) and every partial is folded by one launch.
 #include "common.h"
 #include "gemm_f32.h"
+#include "rng.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -312,7 +313,9 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
                                                        const float* __restrict__ eps,
                                                        const float* __restrict__ given, int64_t M, int A,
                                                        float* __restrict__ action, float* __restrict__ logprob,
-                                                       float* __restrict__ value) {
+                                                       void* __restrict__ value_out, int value_f16,
+                                                       const catppo_iter_state* __restrict__ rng_state, int rng_step,
+                                                       float* __restrict__ eps_out) {
   constexpr int HL = CPL * 64;
   constexpr int VS = 15;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [16*HL] actor head weights, rows >= A zero
@@ -330,6 +333,12 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
   const float sd = mine ? expf(logstd[slot]) : 1.0f;
   const float var = sd * sd, lsd = logf(sd);
   const float ba = mine ? b4a[slot] : 0.0f;
+  // on-device action noise: Philox4x32-10 keyed by the run's seed, counter {env, quad, step, iteration}
+  uint32_t rk0 = 0, rk1 = 0, rit = 0;
+  if (rng_state != nullptr) {
+    const uint64_t sd64 = rng_state->seed;
+    rk0 = (uint32_t)sd64, rk1 = (uint32_t)(sd64 >> 32), rit = (uint32_t)rng_state->iteration;
+  }
   for (int64_t i = wave_id; i < M; i += n_waves) {
     float part[16];
     float dc = 0.0f;
@@ -357,8 +366,17 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
     if (Ha != nullptr) {
       const float mu = tot + ba;
       float a = mu;
-      if (mine && given != nullptr) a = given[i * A + slot];
-      else if (mine && eps != nullptr) a = mu + sd * eps[i * A + slot];   // Normal.sample(): loc + scale*N(0,1)
+      if (mine && given != nullptr) {
+        a = given[i * A + slot];
+      } else if (mine && rng_state != nullptr) {
+        const rng::u32x4 blk = rng::philox4x32_10(rng::u32x4{(uint32_t)i, (uint32_t)(slot >> 2), (uint32_t)rng_step, rit},
+                                                  rk0, rk1);
+        const float e = rng::box_muller_pick(blk, slot & 3);
+        a = mu + sd * e;
+        if (eps_out != nullptr && (lane & 3) == 0) eps_out[i * A + slot] = e;
+      } else if (mine && eps != nullptr) {
+        a = mu + sd * eps[i * A + slot];   // Normal.sample(): loc + scale*N(0,1)
+      }
       const float diff = a - mu;
       const float term = mine ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f;
       float lp = 0.0f;
@@ -367,7 +385,10 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
       if (mine && (lane & 3) == 0) action[i * A + slot] = a;
       if (lane == 0) logprob[i] = lp;
     }
-    if (lane == 0) value[i] = v;
+    if (lane == 0) {
+      if (value_f16) reinterpret_cast<_Float16*>(value_out)[i] = (_Float16)v;   // fp16 rollout plane (RNE)
+      else reinterpret_cast<float*>(value_out)[i] = v;
+    }
   }
 }
 
@@ -382,7 +403,9 @@ __global__ __launch_bounds__(256) void ppo_gather_kernel(const float* __restrict
                                                          const int64_t* __restrict__ inds, int64_t total, int64_t M,
                                                          int Dp, int A, float* __restrict__ xmb,
                                                          float* __restrict__ act, float* __restrict__ scal,
-                                                         double* __restrict__ adv_part) {
+                                                         double* __restrict__ adv_part,
+                                                         const catppo_iter_state* __restrict__ rng_state, int rng_epoch,
+                                                         int adv_f16, int64_t* __restrict__ inds_out) {
   __shared__ int64_t s_idx[kGatherRows];
   const int64_t m0 = (int64_t)blockIdx.y * M;                     // first sample of this minibatch
   const int64_t Mm = (total - m0) < M ? (total - m0) : M;         // its size (the last one may be short)
@@ -395,9 +418,20 @@ __global__ __launch_bounds__(256) void ppo_gather_kernel(const float* __restrict
     return;
   }
   const int rows = (int)((Mm - r0) < kGatherRows ? (Mm - r0) : kGatherRows);
-  inds += m0, xmb += m0 * Dp, act += m0 * A, scal += 4 * m0;
+  xmb += m0 * Dp, act += m0 * A, scal += 4 * m0;
   adv_part += 2 * (int64_t)blockIdx.y * gridDim.x;
-  if (threadIdx.x < rows) s_idx[threadIdx.x] = inds[r0 + threadIdx.x];
+  if (threadIdx.x < rows) {
+    int64_t src;
+    if (rng_state != nullptr) {     // keyed bijection of [0,total): no index array, no sort (rng.h)
+      rng::FeistelPerm perm;
+      perm.init(rng_state->seed, rng_state->iteration, rng_epoch, total);
+      src = perm(m0 + r0 + threadIdx.x);
+      if (inds_out != nullptr) inds_out[m0 + r0 + threadIdx.x] = src;
+    } else {
+      src = inds[m0 + r0 + threadIdx.x];
+    }
+    s_idx[threadIdx.x] = src;
+  }
   __syncthreads();
   const int q4 = Dp / 4;
   for (int f = threadIdx.x; f < rows * q4; f += 256) {
@@ -412,7 +446,7 @@ __global__ __launch_bounds__(256) void ppo_gather_kernel(const float* __restrict
     double a1 = 0.0, a2 = 0.0;
     if (threadIdx.x < rows) {
       const int64_t src = s_idx[threadIdx.x], dst = r0 + threadIdx.x;
-      const float adv = b_adv[src];
+      const float adv = adv_f16 ? (float)reinterpret_cast<const _Float16*>(b_adv)[src] : b_adv[src];
       scal[0 * Mm + dst] = b_logp[src];
       scal[1 * Mm + dst] = adv;
       scal[2 * Mm + dst] = b_ret[src];
@@ -879,66 +913,81 @@ static int mlp_prologue(catppo_ctx* ctx, const catppo_mlp_shape* shape, int64_t 
   return CATPPO_OK;
 }
 
+namespace {
+// rollout policy step shared by catppo_policy_act / _ex / _rng and catppo_value / _ex
+int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
+                const float* eps, const float* given_action, float* action, float* logprob, void* value,
+                int value_dtype, const catppo_iter_state* rng_state, int rng_step, float* eps_out, bool critic_only,
+                void* stream, const char* fn) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, fn)) return rc;
+  CATPPO_CHECK_ARG(ctx, params && x && value && (critic_only || (action && logprob)));
+  CATPPO_CHECK_ARG(ctx, value_dtype == CATPPO_F32 || value_dtype == CATPPO_F16);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int fv = fused_variant(shape);
+  if (fv && value_dtype == CATPPO_F32 && rng_state == nullptr) {
+    FusedArgs f;
+    fill_fused(f, shape, L, params, x, N, w, false);
+    if (!critic_only) f.eps = eps, f.given = given_action, f.action = action, f.logprob = logprob;
+    f.value = static_cast<float*>(value);
+    return launch_fused<false>(ctx, f, fv - 1, critic_only ? 1 : 2, s);   // grid.y == 1: critic task only
+  }
+  forward_hidden(shape, L, params, x, N, w, 0, critic_only ? 1 : 2, s);
+  CATPPO_CHECK_LAUNCH(ctx);
+  const int nl = shape->n_hidden, A = critic_only ? 0 : shape->act_dim;
+  int64_t nblk = cdiv64(N, 4);
+  if (nblk > 2048) nblk = 2048;
+  const float* nul = nullptr;
+  const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
+    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256),
+                       sizeof(float) * 16 * shape->hidden[nl - 1], s, (const float*)w.H[0][nl - 1],
+                       critic_only ? nul : (const float*)w.H[1][nl - 1], params + L.off_w[0][nl],
+                       params + L.off_b[0][nl], critic_only ? nul : params + L.off_w[1][nl],
+                       critic_only ? nul : params + L.off_b[1][nl], critic_only ? nul : params + L.off_logstd,
+                       critic_only ? nul : eps, critic_only ? nul : given_action, N, A, action, logprob, value,
+                       (int)(value_dtype == CATPPO_F16), critic_only ? nullptr : rng_state, rng_step, eps_out);
+  });
+  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", fn);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+}  // namespace
+
 extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
                                  const float* x, int64_t N, const float* eps, const float* given_action,
                                  float* action, float* logprob, float* value, void* stream) {
-  catppo_mlp_layout L;
-  MlpWs w{};
-  if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
-  CATPPO_CHECK_ARG(ctx, params && x && action && logprob && value);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (const int fv = fused_variant(shape)) {
-    FusedArgs f;
-    fill_fused(f, shape, L, params, x, N, w, false);
-    f.eps = eps, f.given = given_action, f.action = action, f.logprob = logprob, f.value = value;
-    return launch_fused<false>(ctx, f, fv - 1, 2, s);
-  }
-  forward_hidden(shape, L, params, x, N, w, 0, 2, s);
-  CATPPO_CHECK_LAUNCH(ctx);
-  const int nl = shape->n_hidden, A = shape->act_dim;
-  int64_t nblk = cdiv64(N, 4);
-  if (nblk > 2048) nblk = 2048;
-  const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
-    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256),
-                       sizeof(float) * 16 * shape->hidden[nl - 1], s,
-                       (const float*)w.H[0][nl - 1], (const float*)w.H[1][nl - 1], params + L.off_w[0][nl],
-                       params + L.off_b[0][nl], params + L.off_w[1][nl], params + L.off_b[1][nl],
-                       params + L.off_logstd, eps, given_action, N, A, action, logprob, value);
-  });
-  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
-  CATPPO_CHECK_LAUNCH(ctx);
-  return CATPPO_OK;
+  return policy_core(ctx, shape, params, x, N, eps, given_action, action, logprob, value, CATPPO_F32, nullptr, 0,
+                     nullptr, false, stream, __func__);
+}
+
+extern "C" int catppo_policy_act_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
+                                    const float* x, int64_t N, const float* eps, const float* given_action,
+                                    float* action, float* logprob, void* value, int value_dtype, void* stream) {
+  return policy_core(ctx, shape, params, x, N, eps, given_action, action, logprob, value, value_dtype, nullptr, 0,
+                     nullptr, false, stream, __func__);
+}
+
+extern "C" int catppo_policy_act_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
+                                     const float* x, int64_t N, const catppo_iter_state* state, int32_t step,
+                                     float* eps_out, float* action, float* logprob, void* value, int value_dtype,
+                                     void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, state != nullptr && step >= 0);
+  return policy_core(ctx, shape, params, x, N, nullptr, nullptr, action, logprob, value, value_dtype, state, step,
+                     eps_out, false, stream, __func__);
 }
 
 extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
                             int64_t N, float* value, void* stream) {
-  catppo_mlp_layout L;
-  MlpWs w{};
-  if (int rc = mlp_prologue(ctx, shape, N, false, &L, &w, __func__)) return rc;
-  CATPPO_CHECK_ARG(ctx, params && x && value);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (const int fv = fused_variant(shape)) {
-    FusedArgs f;
-    fill_fused(f, shape, L, params, x, N, w, false);
-    f.value = value;
-    return launch_fused<false>(ctx, f, fv - 1, 1, s);   // grid.y == 1: critic task only
-  }
-  forward_hidden(shape, L, params, x, N, w, 0, 1, s);
-  CATPPO_CHECK_LAUNCH(ctx);
-  const int nl = shape->n_hidden;
-  int64_t nblk = cdiv64(N, 4);
-  if (nblk > 2048) nblk = 2048;
-  const int rc = dispatch_cpl(shape->hidden[nl - 1], [&](auto cpl) {
-    hipLaunchKernelGGL((head_act_kernel<decltype(cpl)::value>), dim3((unsigned)nblk), dim3(256),
-                       sizeof(float) * 16 * shape->hidden[nl - 1], s,
-                       (const float*)w.H[0][nl - 1], (const float*)nullptr, params + L.off_w[0][nl],
-                       params + L.off_b[0][nl], (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, N, 0, (float*)nullptr,
-                       (float*)nullptr, value);
-  });
-  if (rc) return catppo_fail(ctx, CATPPO_E_ARG, "%s: last hidden width unsupported", __func__);
-  CATPPO_CHECK_LAUNCH(ctx);
-  return CATPPO_OK;
+  return policy_core(ctx, shape, params, x, N, nullptr, nullptr, nullptr, nullptr, value, CATPPO_F32, nullptr, 0,
+                     nullptr, true, stream, __func__);
+}
+
+extern "C" int catppo_value_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
+                               int64_t N, void* value, int value_dtype, void* stream) {
+  return policy_core(ctx, shape, params, x, N, nullptr, nullptr, nullptr, nullptr, value, value_dtype, nullptr, 0,
+                     nullptr, true, stream, __func__);
 }
 
 namespace {
@@ -966,7 +1015,7 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
   // 1. gather the minibatch (ppo.py:300-302,314,331-337 index with mb_inds)
   hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), 1), dim3(256), 0, s, b_obs, b_actions,
                      b_logprobs, b_advantages, b_returns_n, b_values_n, mb_inds, M, M, L.obs_pad, shape->act_dim,
-                     w.xmb, w.act, w.scal, w.adv_part);
+                     w.xmb, w.act, w.scal, w.adv_part, (const catppo_iter_state*)nullptr, 0, 0, (int64_t*)nullptr);
   CATPPO_CHECK_LAUNCH(ctx);
   return minibatch_grad_core(ctx, shape, L, w, hp, params, M, vrms_mean, vrms_var, adv_stats, grad, diag, s);
 }
@@ -985,7 +1034,31 @@ extern "C" int catppo_ppo_gather(catppo_ctx* ctx, const catppo_mlp_shape* shape,
   CATPPO_CHECK_ARG(ctx, n_mb <= 65535);
   hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), (unsigned)n_mb), dim3(256), 0,
                      static_cast<hipStream_t>(stream), b_obs, b_actions, b_logprobs, b_advantages, b_returns_n,
-                     b_values_n, inds, total, M, L.obs_pad, shape->act_dim, x_g, act_g, scal_g, adv_part_g);
+                     b_values_n, inds, total, M, L.obs_pad, shape->act_dim, x_g, act_g, scal_g, adv_part_g,
+                     (const catppo_iter_state*)nullptr, 0, 0, (int64_t*)nullptr);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_ppo_gather_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs,
+                                     const float* b_actions, const float* b_logprobs, const void* b_advantages,
+                                     int adv_dtype, const float* b_returns_n, const float* b_values_n,
+                                     const catppo_iter_state* state, int32_t epoch, int64_t total, int64_t M,
+                                     float* x_g, float* act_g, float* scal_g, double* adv_part_g, int64_t* inds_out,
+                                     void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  catppo_mlp_layout L;
+  CATPPO_CHECK_ARG(ctx, shape && catppo_mlp_layout_of(shape, &L) == CATPPO_OK);
+  CATPPO_CHECK_ARG(ctx, b_obs && b_actions && b_logprobs && b_advantages && b_returns_n && b_values_n && state);
+  CATPPO_CHECK_ARG(ctx, adv_dtype == CATPPO_F32 || adv_dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, x_g && act_g && scal_g && adv_part_g && total >= 1 && total < (int64_t(1) << 31) && M >= 1);
+  const int64_t n_mb = cdiv64(total, M);
+  CATPPO_CHECK_ARG(ctx, n_mb <= 65535);
+  hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), (unsigned)n_mb), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), b_obs, b_actions, b_logprobs,
+                     static_cast<const float*>(b_advantages), b_returns_n, b_values_n, (const int64_t*)nullptr, total,
+                     M, L.obs_pad, shape->act_dim, x_g, act_g, scal_g, adv_part_g, state, (int)epoch,
+                     (int)(adv_dtype == CATPPO_F16), inds_out);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }
@@ -1197,6 +1270,88 @@ extern "C" int catppo_clip_adam(catppo_ctx* ctx, float* params, float* grad, flo
   hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, n_flat,
                      (const double*)part, nb, max_grad_norm, (float)beta1, (float)beta2, (float)(1.0 - beta1),
                      (float)(1.0 - beta2), (float)eps, step_size, bc2_sqrt);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+// ---- clip + Adam with the learning rate and the step count in device memory (catppo_iter_state) ----------------
+namespace {
+__global__ __launch_bounds__(256) void sqnorm_partial_step_kernel(const float* __restrict__ g, int64_t n,
+                                                                  double* __restrict__ part,
+                                                                  catppo_iter_state* __restrict__ st) {
+  __shared__ double sm[4];
+  double a = 0.0;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const double v = (double)g[e];
+    a += v * v;
+  }
+  a = wave_sum_d(a);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    if (blockIdx.x == 0) st->adam_step = st->adam_step + 1;   // read by the NEXT launch (clip_adam_dev_kernel)
+  }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_dev_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                            const double* __restrict__ norm_part, int n_part,
+                                                            float max_norm, double beta1, double beta2, float eps,
+                                                            const catppo_iter_state* __restrict__ st) {
+  __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+  if (threadIdx.x < 64) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < n_part; b += 64) a += norm_part[b];
+    a = wave_sum_d(a);
+    if (threadIdx.x == 0) {
+      const float total = (float)sqrt(a);
+      const float c = max_norm / (total + 1e-6f);
+      s_coef = c > 1.0f ? 1.0f : c;
+      // torch.optim.Adam: bias_correction = 1 - beta ** step (Python doubles), step_size = lr / bias_correction1
+      const double step = (double)st->adam_step;
+      const double bc1 = 1.0 - pow(beta1, step);
+      const double bc2 = 1.0 - pow(beta2, step);
+      s_step_size = (float)(st->lr / bc1);
+      s_bc2_sqrt = (float)sqrt(bc2);
+    }
+  }
+  __syncthreads();
+  const float coef = s_coef, step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+  const float b2 = (float)beta2, one_m_b1 = (float)(1.0 - beta1), one_m_b2 = (float)(1.0 - beta2);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float gr = g[e] * coef;
+    g[e] = gr;
+    float mm = m[e];
+    mm = mm + (gr - mm) * one_m_b1;
+    float vv = v[e] * b2;
+    vv = vv + one_m_b2 * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    m[e] = mm;
+    v[e] = vv;
+    p[e] = p[e] + (-step_size * mm) / denom;
+  }
+}
+}  // namespace
+
+extern "C" int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad, float* exp_avg, float* exp_avg_sq,
+                                    int64_t n_flat, float max_grad_norm, double beta1, double beta2, double eps,
+                                    catppo_iter_state* state, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, params && grad && exp_avg && exp_avg_sq && n_flat >= 1 && state);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  WsCarver ws(ctx);
+  double* part = ws.take<double>(kNormBlocks);
+  CATPPO_NEED_WS(ctx, part);
+  int nb = (int)cdiv64(n_flat, 256 * 4);
+  if (nb > kNormBlocks) nb = kNormBlocks;
+  hipLaunchKernelGGL(sqnorm_partial_step_kernel, dim3(nb), dim3(256), 0, s, (const float*)grad, n_flat, part, state);
+  CATPPO_CHECK_LAUNCH(ctx);
+  int nblk = (int)cdiv64(n_flat, 256 * 4);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(nblk), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, n_flat,
+                     (const double*)part, nb, max_grad_norm, beta1, beta2, (float)eps,
+                     (const catppo_iter_state*)state);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

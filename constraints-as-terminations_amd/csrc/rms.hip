@@ -14,7 +14,8 @@ namespace {
 
 constexpr int kThreads = 256;
 
-__global__ __launch_bounds__(kThreads) void rms_moments_partial(const float* __restrict__ x, int64_t N, int D,
+template <typename XT = float>
+__global__ __launch_bounds__(kThreads) void rms_moments_partial(const XT* __restrict__ x, int64_t N, int D,
                                                                 int64_t ldx, int rows_per_block,
                                                                 double* __restrict__ partial) {
   __shared__ double s1[kThreads], s2[kThreads];
@@ -160,7 +161,8 @@ __global__ __launch_bounds__(kThreads) void rms_final_merge(const double* __rest
   if (threadIdx.x == 0) count[0] = tot;
 }
 
-__global__ __launch_bounds__(kThreads) void rms_normalize(const float* __restrict__ x, int64_t N, int D,
+template <typename XT = float>
+__global__ __launch_bounds__(kThreads) void rms_normalize(const XT* __restrict__ x, int64_t N, int D,
                                                           int64_t ldx, const float* __restrict__ mean,
                                                           const float* __restrict__ var, float eps,
                                                           float* __restrict__ out, int64_t ldo) {
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kThreads) void rms_normalize(const float* __restric
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / D;
     const int c = (int)(e - r * D);
-    const float v = x[r * ldx + c] - s_mean[c];
+    const float v = (float)x[r * ldx + c] - s_mean[c];
     out[r * ldo + c] = v / s_den[c];
   }
 }
@@ -190,7 +192,7 @@ int launch_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ld
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   CATPPO_NEED_WS(ctx, partial);
-  hipLaunchKernelGGL(rms_moments_partial, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
+  hipLaunchKernelGGL(rms_moments_partial<float>, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
   CATPPO_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(rms_moments_final, dim3(1), dim3(kThreads), 0, s, partial, nblk, D, sums);
   CATPPO_CHECK_LAUNCH(ctx);
@@ -266,7 +268,7 @@ extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int
   CATPPO_NEED_WS(ctx, sums);
   if (2 * D <= kFusedMax) {
     const int rows_per_block = (kThreads / Dc) * 16;
-    hipLaunchKernelGGL(rms_moments_partial, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
+    hipLaunchKernelGGL(rms_moments_partial<float>, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
     CATPPO_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL(rms_final_merge, dim3(1), dim3(kThreads), 0, s, (const double*)partial, nblk, (double)N, D, mean,
                        var, count);
@@ -286,7 +288,7 @@ extern "C" int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, 
   CATPPO_CHECK_ARG(ctx, x && mean && var && out && N >= 1 && D >= 1 && D <= 16384 && ldx >= D && ldo >= D);
   int64_t nblk = cdiv64(N * D, kThreads * 4);
   if (nblk > 2048) nblk = 2048;
-  hipLaunchKernelGGL(rms_normalize, dim3((unsigned)nblk), dim3(kThreads), sizeof(float) * 2 * D,
+  hipLaunchKernelGGL(rms_normalize<float>, dim3((unsigned)nblk), dim3(kThreads), sizeof(float) * 2 * D,
                      static_cast<hipStream_t>(stream), x, N, D, ldx, mean, var, eps, out, ldo);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
@@ -303,7 +305,7 @@ extern "C" int catppo_adv_normalize(catppo_ctx* ctx, const float* advantages, in
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2);
   CATPPO_NEED_WS(ctx, partial);
-  hipLaunchKernelGGL(rms_moments_partial, dim3(nblk), dim3(kThreads), 0, s, advantages, n, 1, (int64_t)1, rows_per_block,
+  hipLaunchKernelGGL(rms_moments_partial<float>, dim3(nblk), dim3(kThreads), 0, s, advantages, n, 1, (int64_t)1, rows_per_block,
                      partial);
   CATPPO_CHECK_LAUNCH(ctx);
   int64_t nb = cdiv64(n, kThreads * 4);
@@ -320,6 +322,47 @@ extern "C" int catppo_value_bootstrap(catppo_ctx* ctx, float* rewards, const flo
   CATPPO_CHECK_ARG(ctx, rewards && values && time_outs && N >= 1);
   hipLaunchKernelGGL(value_bootstrap_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), rewards, values, time_outs, gamma, N);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+// ---- fp16 inputs (BASELINE config 5: fp16 rollout planes) ------------------------------------------------------
+extern "C" int catppo_rms_update_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                    float* mean, float* var, float* count, void* stream) {
+  if (x_dtype == CATPPO_F32) return catppo_rms_update(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, count, stream);
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, x && mean && var && count && N >= 1 && D >= 1 && 2 * D <= kFusedMax && ldx >= D);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Dc = D < kThreads ? D : kThreads;
+  const int rows_per_block = (kThreads / Dc) * 16;
+  int nblk = (int)cdiv64(N, rows_per_block);
+  if (nblk > 128) nblk = 128;
+  WsCarver ws(ctx);
+  double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
+  CATPPO_NEED_WS(ctx, partial);
+  hipLaunchKernelGGL(rms_moments_partial<_Float16>, dim3(nblk), dim3(kThreads), 0, s, static_cast<const _Float16*>(x), N,
+                     D, ldx, rows_per_block, partial);
+  CATPPO_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(rms_final_merge, dim3(1), dim3(kThreads), 0, s, (const double*)partial, nblk, (double)N, D, mean,
+                     var, count);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_rms_normalize_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                       const float* mean, const float* var, float eps, float* out, int64_t ldo,
+                                       void* stream) {
+  if (x_dtype == CATPPO_F32)
+    return catppo_rms_normalize(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, eps, out, ldo, stream);
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, x && mean && var && out && N >= 1 && D >= 1 && D <= 16384 && ldx >= D && ldo >= D);
+  int64_t nblk = cdiv64(N * D, kThreads * 4);
+  if (nblk > 2048) nblk = 2048;
+  hipLaunchKernelGGL(rms_normalize<_Float16>, dim3((unsigned)nblk), dim3(kThreads), sizeof(float) * 2 * D,
+                     static_cast<hipStream_t>(stream), static_cast<const _Float16*>(x), N, D, ldx, mean, var, eps, out,
+                     ldo);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

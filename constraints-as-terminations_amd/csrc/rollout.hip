@@ -1,0 +1,536 @@
+// Fused rollout step: everything between the simulator's state update and the next policy forward in TWO launches.
+//
+// The reference spends, per env step, ~15 eager launches + one host sync PER constraint term
+// (cat/constraint_manager.py:39-82,213-229), six launches + a nonzero() sync in CaTEnv.step (cat/cat_env.py:92-121),
+// ~12 launches in RunningMeanStd (cleanrl/ppo.py:12-62) and seven buffer copies (cleanrl/ppo.py:203-226).  Round 1 of
+// this build did the same work in ten launches (env_pre_step, cat_terms, cat_reduce_ema, cat_finish, cat_reset, a
+// masked fill, rollout_store, rms_moments_partial, rms_final_merge, rms_normalize); at 4096 envs every one of them is
+// latency bound (72-92 % of the wave cycles parked), so the step costs ten launch gaps.  Here:
+//
+//   rollout_pre   16-env tiles.  process_action, counters, terminations, raw reward; all constraint terms -> cstr;
+//                 per-workgroup column maxima and fp64 observation moments; the LAST workgroup to finish (device-scope
+//                 ticket) folds the partials in fixed order into the exchange buffer {colmax[K] | sum x, sum x^2 [2D]}.
+//   [env-sharded runs all-reduce the exchange buffer here: MAX for the maxima, SUM for the moments]
+//   rollout_post  32-env tiles.  Every workgroup derives the new running maxima (EMA) and the merged normaliser
+//                 statistics from the exchange buffer on its own (K + D values: cheaper than another launch), then
+//                 does the CaT probabilities / statistics / reward / dones of its envs, the manager-reset statistics
+//                 of the envs that reset (+ zeroing of their accumulators, episode length, action history), the
+//                 rollout-buffer rows and the normalised next-observation rows.  The last workgroup to finish writes
+//                 the new state back (nobody reads it any more in this launch) and folds the reset statistics.
+//
+// Arithmetic: identical statements in identical order to cat_step.hip / rms.hip / env_step.hip (this file is
+// compiled with -ffp-contract=off as well), so the termination masks stay bit-exact.
+#include "terms_eval.h"
+
+namespace {
+
+using namespace terms;
+constexpr int kThreads = 256;
+constexpr int kPostRows = 32;
+constexpr int kMaxObsPerThread = 2;     // D <= 512
+
+struct PreArgs {
+  int64_t N;
+  int A, D, K;
+  const float* action_in;
+  float* action;
+  float* prev_action;
+  int64_t* ep_len;
+  int64_t max_len;
+  const float* hard_reset;
+  int64_t hr_stride;
+  const float* reward_src;
+  int64_t rw_stride;
+  uint8_t* time_outs;
+  uint8_t* terminated;
+  uint8_t* reset;
+  float* reward;
+  const float* forces;
+  int64_t fstride;
+  int H, B;
+  const float* command;
+  int cld;
+  float* cstr;
+  const float* obs_raw;
+  int64_t obs_ld;
+  float* colmax_partial;    // [grid][K]
+  double* osum_partial;     // [grid][2D]
+  float* x_colmax;          // exchange buffer
+  double* x_sums;
+  unsigned int* ticket;
+};
+
+__device__ __forceinline__ bool last_block_arrives(unsigned int* ticket) {
+  // classic "last block folds" hand-shake: make this workgroup's global writes visible device wide, take a ticket,
+  // and if it is the last one make every other workgroup's writes visible to this one
+  __shared__ int s_last;
+  __threadfence();          // release: this thread's global writes, device scope (L2 write-back across XCDs)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
+    if (s_last) *ticket = 0u;   // ready for the next launch (stream ordered)
+  }
+  __syncthreads();
+  const bool last = s_last != 0;
+  if (last) __threadfence();   // acquire: drop stale cache lines before reading the other workgroups' partials
+  return last;
+}
+
+__global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable tab, const PreArgs a) {
+  extern __shared__ float tile[];          // [kRows*K] constraint tile + [K] running column maxima
+  float* cmax = tile + kRows * a.K;
+  const int K = a.K, A = a.A, D = a.D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < K; c += kThreads) cmax[c] = -__builtin_inff();
+  double os1[kMaxObsPerThread], os2[kMaxObsPerThread];
+#pragma unroll
+  for (int q = 0; q < kMaxObsPerThread; ++q) os1[q] = 0.0, os2[q] = 0.0;
+
+  const int64_t n_tiles = (a.N + kRows - 1) / kRows;
+  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+    const int64_t r0 = tl * kRows;
+    const int rows = (int)((a.N - r0) < kRows ? (a.N - r0) : kRows);
+
+    // ---- constraint terms (the action-rate term reads action_in / the not yet shifted action buffer)
+    for (int t = wave; t < tab.n; t += kThreads / 64) {
+      const catppo_term_desc& d = tab.d[t];
+      const int W = d.width;
+      const int col0 = tab.off[t];
+      for (int w = lane; w < rows * W; w += 64) {
+        const int e = w / W, j = w - e * W;
+        tile[e * K + col0 + j] = eval_term(d, r0 + e, j, a.forces, a.fstride, a.H, a.B, a.command, a.cld);
+      }
+    }
+    // ---- counters, terminations, raw reward (cat_env.py:92-97)
+    if (threadIdx.x < rows) {
+      const int64_t i = r0 + threadIdx.x;
+      const int64_t len = a.ep_len[i] + 1;
+      a.ep_len[i] = len;
+      const bool to = len >= a.max_len;
+      const bool term = a.hard_reset[i * a.hr_stride] > 0.5f;
+      a.time_outs[i] = to;
+      a.terminated[i] = term;
+      a.reset[i] = to || term;
+      a.reward[i] = a.reward_src[i * a.rw_stride];
+    }
+    // ---- observation moments of the tile (fp64, fixed order)
+    if (a.obs_raw != nullptr) {
+#pragma unroll
+      for (int q = 0; q < kMaxObsPerThread; ++q) {
+        const int c = threadIdx.x + q * kThreads;
+        if (c < D) {
+          double s1 = os1[q], s2 = os2[q];
+          for (int r = 0; r < rows; ++r) {
+            const double v = (double)a.obs_raw[(r0 + r) * a.obs_ld + c];
+            s1 += v;
+            s2 += v * v;
+          }
+          os1[q] = s1, os2[q] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- flush the tile, running column maxima, and only now shift the action history (process_action)
+    float* dst = a.cstr + r0 * K;
+    for (int e = threadIdx.x; e < rows * K; e += kThreads) dst[e] = tile[e];
+    for (int c = threadIdx.x; c < K; c += kThreads) {
+      float m = cmax[c];
+      for (int r = 0; r < rows; ++r) m = nanmax(m, tile[r * K + c]);
+      cmax[c] = m;
+    }
+    for (int e = threadIdx.x; e < rows * A; e += kThreads) {
+      const int64_t o = r0 * A + e;
+      a.prev_action[o] = a.action[o];
+      a.action[o] = a.action_in[o];
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < K; c += kThreads) a.colmax_partial[(int64_t)blockIdx.x * K + c] = cmax[c];
+  if (a.obs_raw != nullptr) {
+#pragma unroll
+    for (int q = 0; q < kMaxObsPerThread; ++q) {
+      const int c = threadIdx.x + q * kThreads;
+      if (c < D) {
+        a.osum_partial[(int64_t)blockIdx.x * 2 * D + c] = os1[q];
+        a.osum_partial[(int64_t)blockIdx.x * 2 * D + D + c] = os2[q];
+      }
+    }
+  }
+  if (!last_block_arrives(a.ticket)) return;
+  // ---- last workgroup: fold every partial in fixed order (max is order independent; the fp64 sums are folded
+  //      block 0, 1, 2, ... so the result does not depend on which workgroup happens to be last)
+  const int nblk = gridDim.x;
+  for (int c = threadIdx.x; c < K; c += kThreads) {
+    float m = -__builtin_inff();
+#pragma unroll 8
+    for (int b = 0; b < nblk; ++b) m = nanmax(m, __builtin_nontemporal_load(a.colmax_partial + (int64_t)b * K + c));
+    m = (m < 1e-6f) ? 1e-6f : m;      // clamp(min=1e-6); NaN stays NaN like torch
+    a.x_colmax[c] = m;
+  }
+  if (a.obs_raw != nullptr) {
+    for (int c = threadIdx.x; c < 2 * D; c += kThreads) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int b = 0; b < nblk; ++b) s += __builtin_nontemporal_load(a.osum_partial + (int64_t)b * 2 * D + c);
+      a.x_sums[c] = s;
+    }
+  }
+}
+
+struct TermMetaS {
+  int32_t off[kMaxTerms + 1];
+  float dp[kMaxTerms];
+};
+
+struct PostArgs {
+  int64_t N;
+  int A, D, K, n_terms;
+  const float* cstr;
+  float min_p, tau, one_minus_tau;
+  int first_call;
+  float* rm;
+  float* reward;
+  const uint8_t* reset;
+  const uint8_t* time_outs;
+  float* cstr_prob;
+  float* dones;
+  float* ep_viol;
+  float* ep_prob;
+  float* probs;
+  int64_t* ep_len;
+  float* action;
+  float* prev_action;
+  int zero_action;
+  const float* log_prev;
+  float* log_out;
+  void* rewards_t;
+  void* dones_t1;
+  void* true_dones_t1;
+  int planes_f16;
+  const float* obs_raw;
+  int64_t obs_ld;
+  float* obs_mean;
+  float* obs_var;
+  float* obs_count;
+  float obs_eps;
+  double obs_n;
+  float* obs_out;
+  int64_t obs_out_ld;
+  const float* x_colmax;
+  const double* x_sums;
+  double* reset_part;     // [grid][n_terms][2]
+  double* reset_cnt;      // [grid]
+  unsigned int* ticket;
+};
+
+__device__ __forceinline__ void store_plane(void* p, int64_t i, float v, int f16) {
+  if (f16) reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
+  else reinterpret_cast<float*>(p)[i] = v;
+}
+
+__global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a, const TermMetaS meta) {
+  extern __shared__ float smem[];
+  __shared__ double red[2 * kMaxTerms * kPostRows];             // reset statistics per (term, env) of the tile
+  const int K = a.K, D = a.D, nt = a.n_terms;
+  float* col_rm = smem;                                         // [K]
+  float* col_dp = col_rm + K;                                   // [K]
+  float* tile = col_dp + K;                                     // [kPostRows*K]
+  float* tmax = tile + kPostRows * K;                           // [nt*kPostRows]
+  float* s_mean = tmax + nt * kPostRows;                        // [D]
+  float* s_var = s_mean + D;                                    // [D]
+  float* s_den = s_var + D;                                     // [D]
+  __shared__ int s_off[kMaxTerms + 1];
+  __shared__ float s_tot;
+
+  if (threadIdx.x <= nt) s_off[threadIdx.x] = meta.off[threadIdx.x];
+  __syncthreads();
+  // ---- new running maxima (constraint_manager.py:58-61), identical in every workgroup
+  for (int c = threadIdx.x; c < K; c += kThreads) {
+    int t = 0;
+    while (t + 1 < nt && c >= s_off[t + 1]) ++t;
+    const float m = a.x_colmax[c];
+    float r;
+    if (a.first_call) {
+      r = m;
+    } else {
+      const float x = a.rm[c] * a.tau;           // rm.mul_(tau)
+      const float y = a.one_minus_tau * m;       // (1-tau) * cmax
+      r = x + y;                                 // .add_()
+    }
+    col_rm[c] = r;
+    col_dp[c] = meta.dp[t];
+  }
+  // ---- merged observation normaliser (cleanrl/ppo.py:48-62, the op order of rms.hip)
+  if (a.obs_raw != nullptr) {
+    const float cnt = a.obs_count[0];
+    const float nf = (float)a.obs_n;
+    const float tot = cnt + nf;
+    if (threadIdx.x == 0) s_tot = tot;
+    for (int c = threadIdx.x; c < D; c += kThreads) {
+      const double m = a.x_sums[c] / a.obs_n;
+      double v = a.x_sums[D + c] / a.obs_n - m * m;
+      if (v < 0.0) v = 0.0;
+      const float bm = (float)m, bv = (float)v;
+      const float mean = a.obs_mean[c];
+      const float delta = bm - mean;
+      float t = delta * nf;
+      t = t / tot;
+      const float new_mean = mean + t;
+      const float m_a = a.obs_var[c] * cnt;
+      const float m_b = bv * nf;
+      float d2 = delta * delta;
+      d2 = d2 * cnt;
+      d2 = d2 * nf;
+      d2 = d2 / tot;
+      float M2 = m_a + m_b;
+      M2 = M2 + d2;
+      const float new_var = M2 / tot;
+      s_mean[c] = new_mean;
+      s_var[c] = new_var;
+      s_den[c] = sqrtf(new_var + a.obs_eps);
+    }
+  }
+  __syncthreads();
+
+  const int64_t r0 = (int64_t)blockIdx.x * kPostRows;
+  const int rows = (int)((a.N - r0) < kPostRows ? (a.N - r0) : kPostRows);
+  const int n_el = rows * K;
+  const float* src = a.cstr + r0 * K;
+  float* pdst = a.probs ? a.probs + r0 * K : nullptr;
+  for (int e = threadIdx.x; e < n_el; e += kThreads) {
+    const int c = e % K;
+    const float x = src[e];
+    float p = 0.0f;
+    if (x > 0.0f) {
+      float q = x / col_rm[c];
+      q = q < 0.0f ? 0.0f : (q > 1.0f ? 1.0f : q);
+      const float s = q * col_dp[c];
+      p = a.min_p + s;
+    }
+    tile[e] = p;
+    if (pdst) pdst[e] = p;
+  }
+  __syncthreads();
+
+  // ---- per (term, env): max over the term's columns, episode statistics, reset statistics
+  for (int w = threadIdx.x; w < nt * kPostRows; w += kThreads) {
+    const int t = w / kPostRows, e = w - t * kPostRows;
+    double ra = 0.0, rb = 0.0;
+    if (e < rows) {
+      const float* row = tile + e * K;
+      float m = row[s_off[t]];
+      for (int c = s_off[t] + 1; c < s_off[t + 1]; ++c) m = nanmax(m, row[c]);
+      tmax[t * kPostRows + e] = m;
+      const int64_t i = r0 + e;
+      const int64_t gi = (int64_t)t * a.N + i;
+      float v = a.ep_viol[gi] + (m > 0.0f ? 1.0f : 0.0f);
+      float p = a.ep_prob[gi] + m;
+      if (a.reset[i]) {          // ConstraintManager.reset (constraint_manager.py:190-211) for the envs that reset
+        const float L = (float)a.ep_len[i];
+        ra = (double)(v / L);
+        rb = (double)(p / L);
+        v = 0.0f, p = 0.0f;
+      }
+      a.ep_viol[gi] = v;
+      a.ep_prob[gi] = p;
+    }
+    red[w] = ra;
+    red[nt * kPostRows + w] = rb;
+  }
+  __syncthreads();
+  if (threadIdx.x < nt) {
+    const int t = threadIdx.x;
+    double sa = 0.0, sb = 0.0;
+    for (int e = 0; e < kPostRows; ++e) sa += red[t * kPostRows + e], sb += red[nt * kPostRows + t * kPostRows + e];
+    a.reset_part[((int64_t)blockIdx.x * nt + t) * 2] = sa;
+    a.reset_part[((int64_t)blockIdx.x * nt + t) * 2 + 1] = sb;
+  }
+  if (threadIdx.x == kThreads - 1) {
+    double n = 0.0;
+    for (int e = 0; e < rows; ++e) n += a.reset[r0 + e] ? 1.0 : 0.0;
+    a.reset_cnt[blockIdx.x] = n;
+  }
+  // ---- per env: probability, reward, dones (cat_env.py:102-107,118-121), rollout rows, reset bookkeeping
+  if (threadIdx.x < rows) {
+    const int e = threadIdx.x;
+    float p = tmax[e];
+    for (int t = 1; t < nt; ++t) p = nanmax(p, tmax[t * kPostRows + e]);
+    const int64_t i = r0 + e;
+    a.cstr_prob[i] = p;
+    const float omp = 1.0f - p;
+    float r = a.reward[i] * omp;
+    r = (r < 0.0f) ? 0.0f : r;
+    a.reward[i] = r;
+    const bool rs = a.reset[i] != 0;
+    const float dn = rs ? 1.0f : p;
+    if (a.dones) a.dones[i] = dn;
+    if (a.rewards_t != nullptr) {
+      store_plane(a.rewards_t, i, r, a.planes_f16);
+      store_plane(a.dones_t1, i, dn, a.planes_f16);
+      store_plane(a.true_dones_t1, i, a.time_outs[i] ? 1.0f : 0.0f, a.planes_f16);
+    }
+    if (rs) {
+      a.ep_len[i] = 0;
+      if (a.zero_action) {
+        for (int k = 0; k < a.A; ++k) a.action[i * a.A + k] = 0.0f, a.prev_action[i * a.A + k] = 0.0f;
+      }
+    }
+  }
+  // ---- normalised next observation rows
+  if (a.obs_raw != nullptr) {
+    for (int e = threadIdx.x; e < rows * D; e += kThreads) {
+      const int r = e / D, c = e - r * D;
+      const float v = a.obs_raw[(r0 + r) * a.obs_ld + c] - s_mean[c];
+      a.obs_out[(r0 + r) * a.obs_out_ld + c] = v / s_den[c];
+    }
+  }
+  if (!last_block_arrives(a.ticket)) return;
+  // ---- last workgroup: publish the new state, fold the reset statistics
+  for (int c = threadIdx.x; c < K; c += kThreads) a.rm[c] = col_rm[c];
+  if (a.obs_raw != nullptr) {
+    for (int c = threadIdx.x; c < D; c += kThreads) a.obs_mean[c] = s_mean[c], a.obs_var[c] = s_var[c];
+    if (threadIdx.x == 0) a.obs_count[0] = s_tot;
+  }
+  if (a.log_out != nullptr && threadIdx.x < nt) {
+    const int t = threadIdx.x;
+    const int nblk = gridDim.x;
+    double sa = 0.0, sb = 0.0, n = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+      sa += __builtin_nontemporal_load(a.reset_part + ((int64_t)b * nt + t) * 2);
+      sb += __builtin_nontemporal_load(a.reset_part + ((int64_t)b * nt + t) * 2 + 1);
+      n += __builtin_nontemporal_load(a.reset_cnt + b);
+    }
+    if (n > 0.0) {
+      a.log_out[2 * t] = (float)(sa / n) * 100.0f;
+      a.log_out[2 * t + 1] = (float)(sb / n);
+    } else if (a.log_prev != nullptr) {
+      a.log_out[2 * t] = a.log_prev[2 * t];
+      a.log_out[2 * t + 1] = a.log_prev[2 * t + 1];
+    }
+  }
+}
+
+inline uint64_t xchg_sum_offset(int K) { return ((uint64_t)K * sizeof(float) + 15) / 16 * 16; }
+
+int check_step(catppo_ctx* ctx, const catppo_rollout_step* a, const char* fn) {
+  if (!ctx) return CATPPO_E_ARG;
+  if (!a) return catppo_fail(ctx, CATPPO_E_ARG, "%s: null argument block", fn);
+  const bool ok = a->N >= 1 && a->A >= 1 && a->K >= 1 && a->K <= 4096 && a->n_terms >= 1 && a->n_terms <= kMaxTerms &&
+                  a->D >= 0 && a->D <= kMaxObsPerThread * kThreads && a->xchg != nullptr;
+  if (!ok) return catppo_fail(ctx, CATPPO_E_ARG, "%s: sizes out of range (N=%lld A=%d D=%d K=%d n_terms=%d)", fn,
+                              (long long)a->N, a->A, a->D, a->K, a->n_terms);
+  return CATPPO_OK;
+}
+
+}  // namespace
+
+extern "C" uint64_t catppo_rollout_xchg_sum_offset(int K) { return xchg_sum_offset(K); }
+extern "C" uint64_t catppo_rollout_step_sizeof(void) { return sizeof(catppo_rollout_step); }
+extern "C" uint64_t catppo_rollout_xchg_bytes(int K, int D) {
+  return xchg_sum_offset(K) + (uint64_t)2 * (D > 0 ? D : 1) * sizeof(double);
+}
+
+extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream) {
+  if (int rc = check_step(ctx, a, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, a->action_in && a->action && a->prev_action && a->episode_length && a->hard_reset &&
+                            a->reward_src && a->time_outs && a->terminated && a->reset && a->reward && a->desc && a->cstr);
+  CATPPO_CHECK_ARG(ctx, a->obs_raw == nullptr || (a->D >= 1 && a->obs_ld >= a->D));
+  TermTable tab;
+  if (const char* why = build_table(a->desc, a->n_terms, a->forces, a->forces_env_stride, a->H, a->B, a->command,
+                                    a->command_ld, a->K, &tab))
+    return catppo_fail(ctx, CATPPO_E_ARG, "catppo_rollout_pre: %s", why);
+  // the action-rate term (C12) is evaluated BEFORE the action history is shifted inside the same launch: it reads the
+  // incoming action and the still current one instead of action / prev_action
+  for (int t = 0; t < tab.n; ++t) {
+    catppo_term_desc& d = tab.d[t];
+    if (d.x == a->action && d.y == a->prev_action) {
+      const int32_t ld_action = d.x_ld;
+      d.x = a->action_in, d.x_ld = a->A;
+      d.y = a->action, d.y_ld = ld_action;
+    } else {
+      CATPPO_CHECK_ARG(ctx, d.x != a->action && d.x != a->prev_action && d.y != a->action && d.y != a->prev_action);
+    }
+  }
+  const size_t lds = sizeof(float) * ((size_t)kRows * a->K + a->K);
+  CATPPO_CHECK_ARG(ctx, lds <= 150 * 1024);
+  int64_t nblk = cdiv64(a->N, kRows);
+  if (nblk > kMaxBlocks) nblk = kMaxBlocks;
+  WsCarver ws(ctx);
+  float* cpart = ws.take<float>((uint64_t)nblk * a->K);
+  double* opart = ws.take<double>((uint64_t)nblk * 2 * (a->D > 0 ? a->D : 1));
+  CATPPO_NEED_WS(ctx, cpart);
+  CATPPO_NEED_WS(ctx, opart);
+  PreArgs p{};
+  p.N = a->N, p.A = a->A, p.D = a->D, p.K = a->K;
+  p.action_in = a->action_in, p.action = a->action, p.prev_action = a->prev_action;
+  p.ep_len = a->episode_length, p.max_len = a->max_episode_length;
+  p.hard_reset = a->hard_reset, p.hr_stride = a->hard_reset_stride;
+  p.reward_src = a->reward_src, p.rw_stride = a->reward_stride;
+  p.time_outs = a->time_outs, p.terminated = a->terminated, p.reset = a->reset, p.reward = a->reward;
+  p.forces = a->forces, p.fstride = a->forces_env_stride, p.H = a->H, p.B = a->B;
+  p.command = a->command, p.cld = a->command_ld;
+  p.cstr = a->cstr;
+  p.obs_raw = a->obs_raw, p.obs_ld = a->obs_ld;
+  p.colmax_partial = cpart, p.osum_partial = opart;
+  p.x_colmax = static_cast<float*>(a->xchg);
+  p.x_sums = reinterpret_cast<double*>(static_cast<char*>(a->xchg) + xchg_sum_offset(a->K));
+  p.ticket = ctx->tickets + 0;
+  hipLaunchKernelGGL(rollout_pre_kernel, dim3((unsigned)nblk), dim3(kThreads), lds, static_cast<hipStream_t>(stream), tab,
+                     p);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream) {
+  if (int rc = check_step(ctx, a, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, a->cstr && a->term_off && a->term_dp && a->rm && a->cstr_prob && a->ep_viol && a->ep_prob &&
+                            a->reward && a->reset && a->time_outs && a->episode_length);
+  CATPPO_CHECK_ARG(ctx, a->rewards_t == nullptr || (a->dones_t1 && a->true_dones_t1));
+  CATPPO_CHECK_ARG(ctx, a->plane_dtype == CATPPO_F32 || a->plane_dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, a->obs_raw == nullptr || (a->obs_mean && a->obs_var && a->obs_count && a->obs_out &&
+                                                  a->obs_ld >= a->D && a->obs_out_ld >= a->D && a->obs_rows_total >= 1.0));
+  CATPPO_CHECK_ARG(ctx, !a->zero_action_on_reset || (a->action && a->prev_action));
+  TermMetaS meta;
+  int prev = 0;
+  for (int t = 0; t <= a->n_terms; ++t) {
+    if (a->term_off[t] < prev || a->term_off[t] > a->K) return catppo_fail(ctx, CATPPO_E_ARG, "rollout_post: term_off not monotone");
+    prev = meta.off[t] = a->term_off[t];
+  }
+  CATPPO_CHECK_ARG(ctx, a->term_off[0] == 0 && a->term_off[a->n_terms] == a->K);
+  for (int t = 0; t < a->n_terms; ++t) meta.dp[t] = a->term_dp[t];
+  const int nt = a->n_terms, K = a->K, D = a->D;
+  const size_t lds = sizeof(float) * ((size_t)2 * K + (size_t)kPostRows * K + (size_t)nt * kPostRows + (size_t)3 * D);
+  if (lds > 140 * 1024) return catppo_fail(ctx, CATPPO_E_ARG, "rollout_post: K=%d / D=%d too wide for one LDS tile", K, D);
+  const int nblk = (int)cdiv64(a->N, kPostRows);
+  WsCarver ws(ctx);
+  double* rpart = ws.take<double>((uint64_t)nblk * nt * 2);
+  double* rcnt = ws.take<double>((uint64_t)nblk);
+  CATPPO_NEED_WS(ctx, rpart);
+  CATPPO_NEED_WS(ctx, rcnt);
+  PostArgs p{};
+  p.N = a->N, p.A = a->A, p.D = D, p.K = K, p.n_terms = nt;
+  p.cstr = a->cstr;
+  p.min_p = a->min_p, p.tau = a->tau, p.one_minus_tau = a->one_minus_tau, p.first_call = a->first_call;
+  p.rm = a->rm, p.reward = a->reward, p.reset = a->reset, p.time_outs = a->time_outs;
+  p.cstr_prob = a->cstr_prob, p.dones = a->dones, p.ep_viol = a->ep_viol, p.ep_prob = a->ep_prob, p.probs = a->probs;
+  p.ep_len = a->episode_length, p.action = a->action, p.prev_action = a->prev_action;
+  p.zero_action = a->zero_action_on_reset;
+  p.log_prev = a->log_prev, p.log_out = a->log_out;
+  p.rewards_t = a->rewards_t, p.dones_t1 = a->dones_t1, p.true_dones_t1 = a->true_dones_t1;
+  p.planes_f16 = a->plane_dtype == CATPPO_F16;
+  p.obs_raw = a->obs_raw, p.obs_ld = a->obs_ld;
+  p.obs_mean = a->obs_mean, p.obs_var = a->obs_var, p.obs_count = a->obs_count, p.obs_eps = a->obs_eps;
+  p.obs_n = a->obs_rows_total;
+  p.obs_out = a->obs_out, p.obs_out_ld = a->obs_out_ld;
+  p.x_colmax = static_cast<const float*>(a->xchg);
+  p.x_sums = reinterpret_cast<const double*>(static_cast<const char*>(a->xchg) + xchg_sum_offset(K));
+  p.reset_part = rpart, p.reset_cnt = rcnt;
+  p.ticket = ctx->tickets + 1;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_post_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(rollout_post_kernel, dim3(nblk), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p, meta);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}

@@ -30,13 +30,19 @@
 extern "C" {
 #endif
 
-#define CATPPO_VERSION 100 /* 0.1.0 */
+#define CATPPO_VERSION 200 /* 0.2.0 */
 
 #define CATPPO_OK 0
 #define CATPPO_E_ARG (-1)     /* bad argument */
 #define CATPPO_E_HIP (-2)     /* HIP runtime error (launch, alloc) */
 #define CATPPO_E_NODEV (-3)   /* no gfx950 device / device index out of range */
 #define CATPPO_E_WORKSPACE (-4) /* workspace too small: call catppo_reserve first */
+#define CATPPO_E_COMM (-5)    /* RCCL error / communicator not initialised */
+
+/* element types of the buffers that exist in more than one precision (rollout planes, collectives) */
+#define CATPPO_F32 0
+#define CATPPO_F16 1
+#define CATPPO_F64 2
 
 typedef struct catppo_ctx catppo_ctx;
 
@@ -118,11 +124,12 @@ enum catppo_term_kind {
   CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT = 11 /* (|x|-limit)*[|cmd|<dz]     C15 */
 };
 
+#define CATPPO_TERM_MAX_IDS 32
 typedef struct catppo_term_desc {
   int32_t kind;          /* catppo_term_kind */
   int32_t width;         /* output columns */
-  int32_t n_ids;         /* number of joint/body ids used (<= 16) */
-  int32_t ids[16];       /* joint ids, body ids, or ids[0] = column */
+  int32_t n_ids;         /* number of joint/body ids used (<= CATPPO_TERM_MAX_IDS) */
+  int32_t ids[CATPPO_TERM_MAX_IDS]; /* joint ids, body ids, or ids[0] = column (Solo12: 12 joints, 17 bodies) */
   float limit;           /* limit / threshold */
   float aux;             /* dead-zone / min command / desired feet / step_dt */
   const float* x;        /* primary state tensor (N, x_ld) */
@@ -337,6 +344,188 @@ int catppo_ppo_minibatch_grad_packed(catppo_ctx* ctx, const catppo_mlp_shape* sh
 int catppo_clip_adam(catppo_ctx* ctx, float* params, float* grad, float* exp_avg,
                      float* exp_avg_sq, int64_t n_flat, float max_grad_norm, double lr,
                      double beta1, double beta2, double eps, int64_t step, void* stream);
+
+/* ---- device-resident iteration state --------------------------------------------------------------------
+ * Everything that changes from one optimiser step / rollout step / iteration to the next and that a kernel needs
+ * (learning rate, Adam step count, RNG counters) lives in ONE small device struct instead of kernel arguments, so
+ * that the launches of an iteration are identical from one iteration to the next and can be replayed from a
+ * hipGraph (catppo_graph_*), and so that a KL-adaptive schedule can change the learning rate without a host
+ * round trip.  The struct is caller-owned device memory (sizeof(catppo_iter_state) bytes); only the library's
+ * kernels write it. */
+typedef struct catppo_iter_state {
+  uint64_t seed;      /* key of the counter-based RNG (Philox4x32-10 action noise, minibatch permutation) */
+  int64_t iteration;  /* 1-based PPO iteration, incremented by catppo_iter_begin */
+  int64_t adam_step;  /* optimiser steps taken, incremented by catppo_clip_adam_dev */
+  double lr;          /* learning rate used by catppo_clip_adam_dev */
+  double kl_mark;     /* diag[4] (approx-KL sum) at the last catppo_kl_adaptive_lr of this iteration */
+  double n_mark;      /* diag[7] (minibatch count) at that point */
+  double last_kl;     /* KL the schedule last saw (diagnostics) */
+  int64_t reserved;
+} catppo_iter_state;
+
+/* state <- {seed, iteration 0, adam_step 0, lr} */
+int catppo_iter_init(catppo_ctx* ctx, catppo_iter_state* state, uint64_t seed, double lr, void* stream);
+/* start of an iteration: iteration += 1, KL marks <- 0, and the learning-rate schedule
+ *   CATPPO_LR_FIXED   lr = lr0
+ *   CATPPO_LR_LINEAR  lr = (1 - (iteration-1)/num_iterations) * lr0   in double, the reference's expression
+ *                     (cleanrl/ppo.py:196-199)
+ *   CATPPO_LR_KEEP    lr unchanged (it is driven by catppo_kl_adaptive_lr) */
+enum { CATPPO_LR_FIXED = 0, CATPPO_LR_LINEAR = 1, CATPPO_LR_KEEP = 2 };
+int catppo_iter_begin(catppo_ctx* ctx, catppo_iter_state* state, double lr0, int64_t num_iterations, int schedule,
+                      void* stream);
+
+/* catppo_clip_adam with lr and the step count taken from (and the step count advanced in) the device state.
+ * Same arithmetic: the bias corrections 1-beta^step are evaluated in double on the device. */
+int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad, float* exp_avg, float* exp_avg_sq,
+                         int64_t n_flat, float max_grad_norm, double beta1, double beta2, double eps,
+                         catppo_iter_state* state, void* stream);
+
+/* KL-adaptive learning rate, device side (no host sync).  Two calls so that an env-sharded run can put its
+ * all-reduce between them:
+ *   catppo_kl_mean        kl_out[0] = (diag[4] - kl_mark) / (diag[7] - n_mark): the mean approx-KL of the minibatches
+ *                         processed since the previous call of this iteration (the marks then advance).  With
+ *                         inv_global_batch = 1/(M*world) in the minibatch calls the per-rank values SUM to the
+ *                         global mean, which is what skrl's all_reduce(kl, SUM)/world_size computes.
+ *   catppo_kl_adaptive_lr kl > threshold*kl_factor : lr = max(lr / lr_factor, min_lr)
+ *                         kl < threshold/kl_factor : lr = min(lr * lr_factor, max_lr)
+ * replaces: skrl/ppo.py:558-567 (scheduler.step(kl) after the KL all-reduce) with skrl's published KLAdaptiveLR rule
+ * (kl_factor 2, lr_factor 1.5, min_lr 1e-6, max_lr 1e-2; threshold skrl_ppo_cfg.yaml:49-51 = 0.01) - rl_games'
+ * `lr_schedule: adaptive` (rl_games_cat_solo.yaml:64-66, kl_threshold 0.008) is the same rule.  Neither library
+ * is vendored in the reference: the rule itself is PARITY UNPINNED, the call site and the reduction are pinned. */
+int catppo_kl_mean(catppo_ctx* ctx, catppo_iter_state* state, const float* diag, float* kl_out, void* stream);
+int catppo_kl_adaptive_lr(catppo_ctx* ctx, catppo_iter_state* state, const float* kl, double kl_threshold,
+                          double kl_factor, double lr_factor, double min_lr, double max_lr, void* stream);
+
+/* ---- on-device randomness ---------------------------------------------------------------------------------
+ * catppo_policy_act_rng: catppo_policy_act whose N(0,1) action noise comes from Philox4x32-10 + Box-Muller inside
+ * the head kernel (replaces Normal.sample(), cleanrl/ppo.py:111): element (env i, dim k) of rollout step `step`
+ * of iteration state->iteration uses counter {i, k/4, step, iteration}, key = state->seed, lane k%4 of the block.
+ * eps_out ([N,A], may be NULL) receives the noise used, so a parity test can replay it through the oracle.
+ * value_dtype: CATPPO_F32, or CATPPO_F16 to store `value` as IEEE half (fp16 rollout planes). */
+int catppo_policy_act_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
+                          int64_t N, const catppo_iter_state* state, int32_t step, float* eps_out, float* action,
+                          float* logprob, void* value, int value_dtype, void* stream);
+/* fp16 `value` output for the supplied-noise form and the critic-only form */
+int catppo_policy_act_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
+                         int64_t N, const float* eps, const float* given_action, float* action, float* logprob,
+                         void* value, int value_dtype, void* stream);
+int catppo_value_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
+                    void* value, int value_dtype, void* stream);
+
+/* catppo_ppo_gather whose permutation is computed on the fly (replaces torch.randperm, cleanrl/ppo.py:295):
+ * sample j of the epoch reads row P(j), P = a keyed bijection of [0,total) (4-round Feistel network on the next
+ * power of four with cycle walking, round keys from Philox(seed; iteration, epoch)).  No index array, no sort.
+ * inds_out ([total] int64, may be NULL) receives P for parity tests.  adv_dtype: element type of b_advantages
+ * (CATPPO_F16 for fp16 rollout planes; widened on the way into the packed buffers). */
+int catppo_ppo_gather_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs, const float* b_actions,
+                          const float* b_logprobs, const void* b_advantages, int adv_dtype, const float* b_returns_n,
+                          const float* b_values_n, const catppo_iter_state* state, int32_t epoch, int64_t total,
+                          int64_t M, float* x_g, float* act_g, float* scal_g, double* adv_part_g, int64_t* inds_out,
+                          void* stream);
+
+/* ---- fp16 rollout planes (BASELINE config 5) ------------------------------------------------------------------
+ * catppo_rollout_store_ex: catppo_rollout_store with the three destination rows in `dtype`.
+ * catppo_rms_update_ex / catppo_rms_normalize_ex: RunningMeanStd over an input of `x_dtype` (widened exactly;
+ * statistics, state and output stay fp32). */
+int catppo_rollout_store_ex(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
+                            void* rewards_t, void* dones_t1, void* true_dones_t1, int dtype, int64_t N, void* stream);
+int catppo_rms_update_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx, float* mean,
+                         float* var, float* count, void* stream);
+int catppo_rms_normalize_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
+                            const float* mean, const float* var, float eps, float* out, int64_t ldo, void* stream);
+
+/* ---- GAE scan mode -----------------------------------------------------------------------------------------------
+ * mode CATPPO_GAE_SERIAL : one lane per env walks t = T-1..0 (catppo_gae_ex; bit-exact with the reference loop).
+ * mode CATPPO_GAE_SCAN   : the time axis of an env is split over the 2^k lanes of a lane group; every lane composes
+ *   the affine maps A -> delta_t + c_t * A of its chunk, the group combines them with a wavefront-shuffle suffix
+ *   scan, then every lane replays its chunk from the incoming value.  Fills the chip at small N (4096 envs: 64 waves
+ *   serial, up to 1024 in scan mode); the composition reassociates the recurrence, so results agree with the serial
+ *   mode to ~1e-6 relative (tests hold 1e-5), not bit for bit.  CleanRL recurrence (kind 0), fp32 planes. */
+enum { CATPPO_GAE_SERIAL = 0, CATPPO_GAE_SCAN = 1 };
+int catppo_gae_mode(catppo_ctx* ctx, int mode, const float* rewards, const float* values, const float* dones,
+                    const float* true_dones, const float* next_value, const float* next_done,
+                    const float* next_true_done, float gamma, float gamma_lambda, float* advantages, float* returns,
+                    int T, int64_t N, void* stream);
+
+/* ---- fused rollout step ------------------------------------------------------------------------------------------
+ * Everything between the simulator's state update and the next policy forward, in TWO launches instead of ten:
+ *   launch 1 (16-env tiles)  process_action, episode counters, terminations, reward pick-up (catppo_env_pre_step);
+ *                            all constraint terms -> cstr (catppo_cat_terms); per-workgroup column maxima and fp64
+ *                            observation moments; the last workgroup to finish folds them (fixed order) into
+ *                            xchg = {colmax[K] floored at 1e-6 | sum x [D] | sum x^2 [D]}
+ *   [env-sharded: MAX / SUM all-reduce of xchg here]
+ *   launch 2 (32-env tiles)  running-max EMA, probabilities, per-env / per-term maxima, episode statistics, reward
+ *                            scaling, float dones (catppo_cat_apply); ConstraintManager.reset statistics of the envs
+ *                            that reset + zeroing (catppo_cat_reset), episode_length / action history reset;
+ *                            rollout-buffer rows (catppo_rollout_store); Chan merge of the observation normaliser
+ *                            and normalised observation row obs[step+1] (catppo_rms_update + _normalize).  Every
+ *                            workgroup derives the new running maxima / normaliser state redundantly from xchg; the
+ *                            last one to finish writes them back and folds the reset statistics into `log_out`.
+ * Same arithmetic and results as the separate calls (bit-exact: CaT, rewards, dones, statistics; normaliser: same
+ * fp64 sums folded in a different fixed order, <= 1 ulp of the fp32 state). */
+typedef struct catppo_rollout_step {
+  /* sizes */
+  int64_t N;
+  int32_t A, D, K, n_terms;
+  /* pre-step (catppo_env_pre_step) */
+  const float* action_in; float* action; float* prev_action;
+  int64_t* episode_length; int64_t max_episode_length;
+  const float* hard_reset; int64_t hard_reset_stride;
+  const float* reward_src; int64_t reward_stride;
+  uint8_t* time_outs; uint8_t* terminated; uint8_t* reset; float* reward;
+  /* constraint terms (catppo_cat_terms) */
+  const catppo_term_desc* desc;       /* HOST array [n_terms] */
+  const float* forces; int64_t forces_env_stride; int32_t H, B;
+  const float* command; int32_t command_ld;
+  float* cstr;
+  /* CaT (catppo_cat_apply) */
+  const int32_t* term_off; const float* term_dp;   /* HOST arrays */
+  float min_p, tau, one_minus_tau; int32_t first_call;
+  float* rm; float* cstr_prob; float* dones; float* ep_viol; float* ep_prob; float* probs;
+  /* ConstraintManager.reset statistics: log_out[2*n_terms] <- means over the envs that reset (log_prev if none) */
+  const float* log_prev; float* log_out;
+  int32_t zero_action_on_reset;
+  /* rollout rows */
+  void* rewards_t; void* dones_t1; void* true_dones_t1; int32_t plane_dtype;
+  /* observation normaliser + next observation row */
+  const float* obs_raw; int64_t obs_ld;
+  float* obs_mean; float* obs_var; float* obs_count; float obs_eps; double obs_rows_total;
+  float* obs_out; int64_t obs_out_ld;
+  /* exchange buffer, device: K floats (as doubles' storage is separate) - see catppo_rollout_xchg_bytes */
+  void* xchg;
+} catppo_rollout_step;
+uint64_t catppo_rollout_xchg_bytes(int K, int D);
+uint64_t catppo_rollout_step_sizeof(void);   /* sizeof(catppo_rollout_step): lets a binding check its struct layout */
+/* phase 1 and phase 2 (call both back to back on one GPU; all-reduce xchg in between when env-sharded:
+ * floats [0,K) with MAX, doubles at byte offset catppo_rollout_xchg_sum_offset(K) [2*D] with SUM) */
+uint64_t catppo_rollout_xchg_sum_offset(int K);
+int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
+int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
+
+/* ---- HIP graphs ------------------------------------------------------------------------------------------------
+ * Capture every launch the library (or anything else) enqueues on `stream` between begin and end into a hipGraph,
+ * instantiate it, and replay it with one call.  `stream` must not be the legacy default stream.  No library call
+ * allocates or synchronises while a capture is active (catppo_reserve returns CATPPO_E_ARG then). */
+int catppo_graph_begin(catppo_ctx* ctx, void* stream);
+int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, int* n_nodes);
+int catppo_graph_launch(catppo_ctx* ctx, int graph_id, void* stream);
+int catppo_graph_destroy(catppo_ctx* ctx, int graph_id);
+
+/* ---- collectives (RCCL over xGMI, one process per GPU) ---------------------------------------------------------
+ * librccl is loaded at run time (dlopen) by the first of these calls; the library has no link-time dependency on it.
+ * catppo_comm_unique_id: rank 0 creates the id (128 bytes) and ships it to the other ranks by any means (the host
+ * code here uses the launcher's rendezvous store); every rank then calls catppo_comm_init.  The collectives are
+ * in place, enqueue on `stream`, are capturable in a hipGraph, and reduce `count` elements of `dtype`
+ * (CATPPO_F32 / CATPPO_F64).   semantics replaced: skrl/ppo.py:126-131 (parameter broadcast), :534-537 (gradient
+ * reduction), :562-564 (KL all-reduce); the CleanRL path of the reference has no collective. */
+enum { CATPPO_SUM = 0, CATPPO_MAX = 1 };
+#define CATPPO_UNIQUE_ID_BYTES 128
+int catppo_comm_unique_id(uint8_t* out128);
+int catppo_comm_init(catppo_ctx* ctx, int rank, int world, const uint8_t* unique_id128);
+int catppo_comm_world(catppo_ctx* ctx);   /* 0 = no communicator */
+int catppo_comm_destroy(catppo_ctx* ctx);
+int catppo_allreduce(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int op, void* stream);
+int catppo_broadcast(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int root, void* stream);
 
 #ifdef __cplusplus
 }

@@ -100,6 +100,12 @@ class CaTEnvOracle:
         if len(ids):
             self.last_log = self.mgr.reset(ids, self.episode_length)
         self.episode_length[ids] = 0
+        # IsaacLab ActionManager.reset(env_ids): the action history of the reset envs restarts from zero
+        # (self.action may alias the caller's array: copy before writing)
+        if len(ids):
+            self.action, self.prev_action = self.action.copy(), self.prev_action.copy()
+            self.action[ids] = 0
+            self.prev_action[ids] = 0
         obs = {"policy": torch.from_numpy(self._f(slab, "obs").copy())}
         return obs, torch.from_numpy(reward), torch.from_numpy(dones), torch.from_numpy(time_outs), {"log": self.last_log}
 

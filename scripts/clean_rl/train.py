@@ -4,11 +4,12 @@ Same command line as the reference (scripts/clean_rl/train.py):
 
     python scripts/clean_rl/train.py --task=Isaac-Velocity-CaT-Flat-Solo12-v0 --headless
 
-IsaacLab's AppLauncher / hydra / gymnasium are used when importable; on an AMD box (no Isaac Sim)
-the task registry and config classes of ``cat_envs.shim`` take over and the env is driven by the
-device-resident synthetic Solo12 stream.  ``key=value`` overrides after the flags are applied to
-the env / agent configs (``env.scene.num_envs=1024 agent.minibatch_size=8192``), standing in for
-the hydra overrides of the reference.
+Isaac Sim cannot run on an AMD box, so the task registry and config classes of ``cat_envs.shim``
+stand in for gymnasium / hydra and the env is driven by the device-resident synthetic Solo12 stream;
+only AppLauncher's argument definitions are picked up when IsaacLab happens to be importable.
+``key=value`` overrides after the flags are applied to the env / agent configs
+(``env.scene.num_envs=1024 agent.minibatch_size=8192``) - the same dotted syntax as the reference's
+hydra overrides, resolved here without hydra.
 """
 import argparse
 import os
@@ -94,17 +95,22 @@ def main(argv=None):
     env_cfg.scene.num_envs = args_cli.num_envs if args_cli.num_envs is not None else env_cfg.scene.num_envs
     agent_cfg.num_iterations = (args_cli.num_iterations if args_cli.num_iterations is not None
                                 else agent_cfg.num_iterations)
-    env_cfg.seed = agent_cfg.seed
+    # env-sharded runs (torchrun): every rank owns its own block of --num_envs environments with its own stream
+    # (seed + rank, like the reference's distributed front-ends: scripts/rl_games/train.py:100-107), so the
+    # all-reduces combine distinct shards; rank 0 alone writes the run directory
+    rank = int(os.environ.get("RANK", "0")) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0
+    env_cfg.seed = agent_cfg.seed + rank
     env_cfg.sim.device = args_cli.device if args_cli.device is not None else env_cfg.sim.device
     apply_overrides({"env": env_cfg, "agent": agent_cfg}, [o for o in overrides if "=" in o])
 
     log_root_path = os.path.abspath(os.path.join("logs", "clean_rl", agent_cfg.experiment_name))
     print(f"[INFO] Logging experiment in directory: {log_root_path}")
     log_dir = os.path.join(log_root_path, datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
-    dump_cfg(os.path.join(log_dir, "params", "env.yaml"), env_cfg)
-    dump_cfg(os.path.join(log_dir, "params", "agent.yaml"), agent_cfg)
-    dump_cfg(os.path.join(log_dir, "params", "env.pkl"), env_cfg)
-    dump_cfg(os.path.join(log_dir, "params", "agent.pkl"), agent_cfg)
+    if rank == 0:
+        dump_cfg(os.path.join(log_dir, "params", "env.yaml"), env_cfg)
+        dump_cfg(os.path.join(log_dir, "params", "agent.yaml"), agent_cfg)
+        dump_cfg(os.path.join(log_dir, "params", "env.pkl"), env_cfg)
+        dump_cfg(os.path.join(log_dir, "params", "agent.pkl"), agent_cfg)
 
     env = make(args_cli.task, cfg=env_cfg, render_mode="rgb_array" if args_cli.video else None)
     if args_cli.video:

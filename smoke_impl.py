@@ -27,7 +27,9 @@ def make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden=(512, 256, 1
     env_cfg.seed = seed
     env_cfg.synthetic.obs_dim = obs_dim
     env_cfg.synthetic.stream_steps = stream_steps or max(2 * num_steps, 16)
-    if six_terms:
+    if six_terms == "two":                      # BASELINE config 1: 2 ConstraintTerms
+        env_cfg.constraints, env_cfg.curriculum = E.TwoConstraintsCfg(), E.TwoCurriculumCfg()
+    elif six_terms:                             # BASELINE config 2: 6 ConstraintTerms
         env_cfg.constraints, env_cfg.curriculum = E.SixConstraintsCfg(), E.SixCurriculumCfg()
     agent_cfg.num_steps, agent_cfg.minibatch_size = num_steps, minibatch
     agent_cfg.updates_epochs, agent_cfg.num_iterations = epochs, iters
