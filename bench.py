@@ -4,19 +4,23 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE full CaT-PPO iteration (BASELINE.json metric): T x [obs normaliser
-update+apply, policy/value forward + sample, constraint-term evaluation + CaT step + reward /
-dones epilogue, rollout-buffer writes] + bootstrap value + GAE + value normaliser x2 +
-E epochs x ceil(N*T/M) minibatch steps (gather, forward, losses, backward, [RCCL gradient
-all-reduce], global-norm clip, Adam).  Synthetic streams are generated before the timed region
-and are device resident.  Workload (default) = BASELINE.json configs[1]: 4096 envs x 24, Solo12,
-6 constraint terms (42 columns), 48-d obs, 3x256 MLP;  --workload reference runs the reference's
-own shapes (45-d obs, 13 terms / 78 columns, 512/256/128 MLPs).  Weak scaling: every rank owns
-4096 envs and a 16384-sample minibatch share (global minibatch = 16384 x N).
+A "step" is ONE full CaT-PPO iteration (BASELINE.json metric): T x [policy/value forward + Philox action
+sample, constraint-term evaluation + CaT step + reward / dones epilogue + reset statistics, rollout-buffer rows, obs
+normaliser update + apply] + bootstrap value + GAE + value normaliser x2 + E epochs x ceil(N*T/M) minibatch steps
+(keyed-permutation gather, forward, losses, backward, [RCCL gradient all-reduce], global-norm clip, Adam) + the
+per-iteration diagnostics read-back the reference's logging performs (ppo.py:356-367).  Synthetic streams are generated
+before the timed region and are device resident.  Workload (default) = BASELINE.json configs[1]: 4096 envs x 24,
+Solo12, 6 constraint terms (42 columns), 48-d obs, 3x256 MLP;  --workload reference runs the reference's own shapes
+(45-d obs, 13 terms / 78 columns, 512/256/128 MLPs).
+
+Scaling (--gpus N > 1): default = WEAK (every rank owns the workload's envs and minibatch share: global minibatch =
+16384 x N).  --workload cfg3 is BASELINE configs[2] as written - 16384 envs and a 16384-sample minibatch GLOBAL, sharded
+over the ranks - i.e. STRONG scaling of a fixed job.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -38,12 +42,21 @@ WORKLOADS = {
     "reference": dict(num_envs=4096, num_steps=24, obs_dim=45, hidden=(512, 256, 128), six_terms=False,
                       desc="4096 envs x 24, Solo12 45-d obs, 13 ConstraintTerms (78 cols), 512/256/128 MLPs, 5 epochs x 6 minibatches of 16384"),
     # the other BASELINE.json configs (parity-test cases; measured for orientation, never the headline line)
+    "cfg1": dict(num_envs=64, num_steps=24, obs_dim=48, hidden=(512, 256, 128), six_terms="two", minibatch=512,
+                 desc="64 envs x 24, 48-d obs, 2 ConstraintTerms, reference MLP (plumbing case)"),
+    "cfg3": dict(num_envs=16384, num_steps=24, obs_dim=45, hidden=(512, 256, 128), six_terms=False, strong=True,
+                 desc="BASELINE configs[2] as written: 16384 envs x 24 GLOBAL, full ConstraintsCfg, 512/256/128 MLPs, "
+                      "global minibatch 16384 - envs and minibatch sharded over the ranks (strong scaling)"),
     "cfg3_shard": dict(num_envs=2048, num_steps=24, obs_dim=45, hidden=(512, 256, 128), six_terms=False, minibatch=2048,
-                       desc="one rank's share of config 3: 2048 envs x 24, full ConstraintsCfg, 512/256/128 MLPs, minibatches of 2048"),
+                       desc="one rank's share of config 3 at 8 GPUs: 2048 envs x 24, full ConstraintsCfg, 512/256/128 MLPs, minibatches of 2048"),
     "cfg4": dict(num_envs=4096, num_steps=48, obs_dim=235, hidden=(256, 256, 256), six_terms=True,
                  desc="4096 envs x 48, 235-d obs (48 + 187 height scan), 6 ConstraintTerms, 3x256 MLP, minibatches of 16384"),
     "cfg5_envs": dict(num_envs=32768, num_steps=24, obs_dim=48, hidden=(256, 256, 256), six_terms=False,
-                      desc="32768 envs x 24, 48-d obs, 13 ConstraintTerms with mixed hard/soft max_p, 3x256 MLP, minibatches of 16384"),
+                      desc="32768 envs x 24, 48-d obs, 13 ConstraintTerms with mixed hard/soft max_p, 3x256 MLP, minibatches of 16384 (fp32 planes / fp32 MFMA)"),
+    "cfg5": dict(num_envs=32768, num_steps=24, obs_dim=48, hidden=(256, 256, 256), six_terms=False,
+                 rollout_dtype="fp16", mlp_precision="bf16",
+                 desc="BASELINE configs[4]: 32768 envs x 24, fp16 rollout planes + bf16-operand MLP MFMA, 13 ConstraintTerms "
+                      "with mixed hard/soft max_p, 3x256 MLP, minibatches of 16384 (reduced precision: not the headline)"),
 }
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA dense peak
@@ -56,15 +69,40 @@ def fwd_macs(obs_dim, hidden, act_dim=12):
     return 2 * body + hidden[-1] * (act_dim + 1)
 
 
-def build(workload, seed, device_index, mlp_precision="fp32"):
+def csrc_hash():
+    """identity of the kernel sources: PMC traffic summaries under profiles/ are stamped with it"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "constraints-as-terminations_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def shard_of(w, world, rank):
+    """(envs, minibatch) of this rank"""
+    from cat_envs import parallel
+    mb = w.get("minibatch", 16384)
+    if not w.get("strong"):
+        return w["num_envs"], mb
+    sl = parallel.shard_slice(w["num_envs"], rank, world)
+    return sl.stop - sl.start, max(mb // world, 1)
+
+
+def build(workload, seed, device_index, mlp_precision=None, world=1, rank=0, overrides=None):
     import smoke_impl
     from cat_envs.shim import make
     from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
     w = WORKLOADS[workload]
-    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(w["num_envs"], w["num_steps"], w.get("minibatch", 16384), 5, 2000, w["hidden"],
+    n_envs, mb = shard_of(w, world, rank)
+    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(n_envs, w["num_steps"], mb, 5, 2000, w["hidden"],
                                                     w["six_terms"], obs_dim=w["obs_dim"], stream_steps=48, seed=seed)
     env_cfg.sim.device = f"cuda:{device_index}"
-    agent_cfg.mlp_precision = mlp_precision
+    agent_cfg.mlp_precision = mlp_precision or w.get("mlp_precision", "fp32")
+    agent_cfg.rollout_dtype = w.get("rollout_dtype", "fp32")
+    for k, v in (overrides or {}).items():
+        setattr(agent_cfg, k, v)
     env = make(task, cfg=env_cfg)
     trainer = PPOTrainer(env, agent_cfg)
     return env, trainer, agent_cfg
@@ -103,7 +141,7 @@ def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=15.0):
     cpu_env = env_oracle.from_device_env(env)
     ag = ppo_oracle.AgentOracle(trainer.D, trainer.A, w["hidden"], seed=0)
     cfg = {k: getattr(agent_cfg, k) for k in ppo_oracle.PPOOracle.DEFAULT_CFG}
-    orc = ppo_oracle.PPOOracle(cpu_env, w["num_envs"], trainer.D, trainer.A, cfg=cfg, hidden=w["hidden"], agent=ag)
+    orc = ppo_oracle.PPOOracle(cpu_env, trainer.N, trainer.D, trainer.A, cfg=cfg, hidden=w["hidden"], agent=ag)
     orc.run_iteration()                                   # warm-up (allocator, thread pool)
     for k in orc.timers:
         orc.timers[k] = 0.0
@@ -113,32 +151,40 @@ def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=15.0):
         n += 1
     dt = time.perf_counter() - t0
     tm = orc.timers
-    steps = w["num_envs"] * w["num_steps"] * n
+    steps = trainer.N * w["num_steps"] * n
     return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} full iterations of {w['num_envs']}x{w['num_steps']} (5 epochs, minibatches of "
-                      f"{min(w.get('minibatch', 16384), w['num_envs'] * w['num_steps'])}) "
-                      f"after 1 warm-up iteration, {dt:.1f} s wall",
+            "sample": f"{n} full iterations of {trainer.N}x{w['num_steps']} (5 epochs, minibatches of "
+                      f"{min(trainer.mb, trainer.batch)}) after 1 warm-up iteration, {dt:.1f} s wall",
             "phase_ms_per_iteration": {"rollout_fwd_and_env": 1e3 * tm["rollout"] / n, "cat_env_step": 1e3 * tm["env"] / n,
                                        "gae": 1e3 * tm["gae"] / n, "update": 1e3 * tm["update"] / n}}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch of the dominant kernel group from the committed PMC summary (separate
-    rocprofv3 --pmc passes cannot run inside the timed process); None when no summary matches"""
-    path = os.path.join(ROOT, "profiles", f"r1_pmc_traffic_{workload}.json")
+def pmc_traffic(workload, tag):
+    """HBM bytes per launch of the dominant kernel group from the committed PMC summary (separate rocprofv3 --pmc
+    passes cannot run inside the timed process).  The summary carries the hash of the kernel sources it was measured
+    on: a stale one is reported as null, not as a number."""
+    path = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{workload}.json")
     try:
         with open(path) as f:
-            return json.load(f)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None, None, f"no PMC summary at profiles/{os.path.basename(path)}"
+    if d.get("csrc_hash") != csrc_hash():
+        return None, None, (f"profiles/{os.path.basename(path)} was measured on kernel sources {d.get('csrc_hash')}, the "
+                            f"tree is {csrc_hash()}: re-run tools/profile_bench.sh")
+    return d.get("hbm_bytes_per_launch"), os.path.basename(path), None
 
 
-def gae_roofline(nat, T, N, reps=50):
+def gae_roofline(nat, T, N, reps=50, mode=None):
+    from cat_envs import native
     dev = "cuda"
     x = [torch.rand(T, N, device=dev) for _ in range(4)]
     nv, nd, ntd = (torch.rand(N, device=dev) for _ in range(3))
     adv, ret = torch.empty(T, N, device=dev), torch.empty(T, N, device=dev)
-    f = lambda: nat.gae(x[0], x[1], x[2], x[3], nv, nd, ntd, 0.99, 0.95, adv, ret)
+    if mode is None:
+        f = lambda: nat.gae(x[0], x[1], x[2], x[3], nv, nd, ntd, 0.99, 0.95, adv, ret)
+    else:
+        f = lambda: nat.gae_mode(mode, x[0], x[1], x[2], x[3], nv, nd, ntd, 0.99, 0.95, adv, ret)
     for _ in range(5):
         f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -150,7 +196,8 @@ def gae_roofline(nat, T, N, reps=50):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     byt = 24.0 * T * N + 12.0 * N
-    return {"T": T, "N": N, "us": us, "GBps": byt / us / 1e3, "frac": byt / us / 1e3 / HBM_PEAK_GBPS}
+    return {"T": T, "N": N, "us": us, "GBps": byt / us / 1e3, "frac": byt / us / 1e3 / HBM_PEAK_GBPS,
+            "mode": {None: "serial_exact", native.GAE_SCAN: "scan", native.GAE_SERIAL: "serial_exact"}[mode]}
 
 
 def main():
@@ -160,9 +207,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mlp-precision", choices=("fp32", "bf16"), default="fp32",
+    ap.add_argument("--mlp-precision", choices=("fp32", "bf16"), default=None,
                     help="fp32 = the reference's numerics (the headline metric).  bf16 = hidden-layer GEMM operands "
                          "rounded to bf16, fp32 accumulation / master weights (BASELINE config 5): NOT the parity mode")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
+                    help="PPO cfg override, e.g. --set graph_update=True --set rng=torch --set fused_rollout=False")
+    ap.add_argument("--profile-tag", default="r2", help="prefix of the PMC summaries under profiles/")
     ap.add_argument("--seed", type=int, default=42)
     a = ap.parse_args()
 
@@ -176,15 +226,26 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
+        # torch.distributed is the rendezvous (unique-id exchange, barrier); the data-path collectives are
+        # catppo_allreduce on libcatppo's own RCCL communicator
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
     else:
         torch.cuda.set_device(0)
     if a.gpus != world and rank == 0:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
 
+    import ast
+    overrides = {}
+    for kv in a.set:
+        k, _, v = kv.partition("=")
+        try:
+            overrides[k] = ast.literal_eval(v)
+        except (ValueError, SyntaxError):
+            overrides[k] = v
     w = WORKLOADS[a.workload]
-    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision)
+    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision, world, rank, overrides)
     nat = trainer.nat
+    from cat_envs import parallel
 
     def barrier():
         if world > 1:
@@ -192,11 +253,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
-        trainer.run_iteration(log=False)
+        trainer.run_iteration(log=True)
 
     # ---- timed region: exactly K iterations between barrier + synchronize
-    # HIP events bracket every catppo_ppo_minibatch_grad call (the dominant kernel group) on the stream
-    # it is enqueued on (torch's current stream)
+    # HIP events bracket every catppo_ppo_minibatch_grad_packed call (the dominant kernel group) on the stream it is
+    # enqueued on (the trainer's current stream).  When the update phase is replayed from a hipGraph there are no
+    # per-call host launches to bracket: the group is then timed by an eager replay right after the timed region.
     ev = []
     orig = nat.ppo_minibatch_grad_packed
 
@@ -206,47 +268,88 @@ def main():
         orig(*args, **kw)
         e1.record()
         ev.append((e0, e1))
-    nat.ppo_minibatch_grad_packed = timed_grad
+    if not trainer.graph_update:
+        nat.ppo_minibatch_grad_packed = timed_grad
+    trainer.time_phases = True
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        trainer.run_iteration(log=False)
+        trainer.run_iteration(log=True)           # log=True: the per-iteration diagnostics read-back is inside the metric
     barrier()
     dt = time.perf_counter() - t0
     nat.ppo_minibatch_grad_packed = orig
+    phases = trainer.phase_summary()
+    trainer.time_phases = False
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    steps_total = w["num_envs"] * w["num_steps"] * world * a.steps
+    env_total = trainer.n_envs_global if world > 1 else float(trainer.N)
+    steps_total = env_total * w["num_steps"] * a.steps
     value = steps_total / dt
 
+    # the same K iterations without the read-back (host free to run ahead), for comparison only
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.run_iteration(log=False)
+    barrier()
+    dt_nolog = time.perf_counter() - t1
+
     if rank == 0:
+        M = min(trainer.mb, trainer.batch)
+        if trainer.graph_update:                   # eager replay of the group on the data of the last iteration
+            trainer._update_buffers()
+            for _ in range(12):
+                timed_grad(trainer.agent.shape, trainer.hp, trainer.agent.flat, trainer._x_g, trainer._act_g,
+                           trainer._scal_g, trainer._advp_g, M, trainer.agent.value_rms.running_mean,
+                           trainer.agent.value_rms.running_var, None, trainer.grad, trainer.diag)
+            torch.cuda.synchronize()
+            ev[:] = ev[2:]
         grad_us = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
         macs = fwd_macs(w["obs_dim"], w["hidden"])
-        M = min(w.get("minibatch", 16384), w["num_envs"] * w["num_steps"])
         flops_per_launch = 3 * 2 * macs * M                       # fwd + bwd = 3x fwd, per minibatch
         ach = flops_per_launch / grad_us / 1e6
-        bf16 = a.mlp_precision == "bf16"
+        bf16 = agent_cfg.mlp_precision == "bf16"
         peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
-        traffic = None if bf16 else pmc_traffic(a.workload)
+        traffic, traffic_src, traffic_note = (None, None, "bf16 mode: no PMC pass") if bf16 else \
+            pmc_traffic(a.workload, a.profile_tag)
+        if traffic_note and not bf16:
+            print(f"[bench] roofline.traffic = null: {traffic_note}", file=sys.stderr)
+        n_mb_steps = int(agent_cfg.updates_epochs) * ((trainer.batch + M - 1) // M)
+        it_flops = (w["num_steps"] * trainer.N * 2 * macs) + n_mb_steps * flops_per_launch     # rollout fwd + update
+        from cat_envs import native
         out = {
             "metric": "env-steps/s CaT-PPO iteration (rollout + GAE + PPO update)", "value": value,
             "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not bf16 else "bf16 GEMM operands, f32 accumulate/params (reduced precision: not the headline)",
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "strong" if w.get("strong") else "weak", "vs_baseline": None,
+            "dtype": ("f32" if not bf16 else "bf16 GEMM operands, f32 accumulate/params (reduced precision: not the headline)")
+                     + ("" if agent_cfg.rollout_dtype == "fp32" else ", f16 rollout planes"),
             "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": w["num_envs"], "horizon": w["num_steps"],
-                       "global_minibatch": M * world, "parallelism": f"env-sharded dp{world}, RCCL all-reduce of the flat gradient"},
+            "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": trainer.N, "envs_total": env_total,
+                       "horizon": w["num_steps"], "minibatch_per_gpu": M, "global_minibatch": M * world,
+                       "parallelism": f"env-sharded dp{world}, catppo_allreduce (RCCL) of the flat gradient",
+                       "rccl_world": nat.comm_world if parallel.native_comm_active() else (world if world > 1 else 0),
+                       "collectives": "libcatppo C ABI (librccl)" if parallel.native_comm_active() else
+                                      ("torch.distributed" if world > 1 else "none"),
+                       "timed_region": "K x run_iteration(log=True): includes the per-iteration diagnostics read-back",
+                       "rng": trainer.rng, "fused_rollout": trainer.sink is not None,
+                       "graph_update": trainer.graph_update, "graph_nodes": trainer.graph_nodes,
+                       "overrides": overrides},
+            "ms_per_step_no_readback": 1e3 * dt_nolog / a.steps,
+            "phases_device_ms": phases,
+            "iteration_tflops": it_flops / (1e9 * dt / a.steps) / 1e3,
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (3 grouped fp32-MFMA forward GEMM launches, "
                          "head+loss, paired split-K dW + dX GEMM launches, partial fold) per " + str(M) + "-sample minibatch",
                          "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic, "avg_launch_us": grad_us,
+                         "traffic": traffic, "avg_launch_us": grad_us, "launches_timed": len(ev),
+                         "timed": "eager replay after the timed region (update phase runs from a hipGraph)"
+                                  if trainer.graph_update else "HIP events inside the timed region",
                          "flops_per_launch": flops_per_launch,
-                         "traffic_source": None if traffic is None else
-                         f"profiles/r1_pmc_traffic_{a.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                         "of this command, FETCH x2 gfx950 correction)"},
-            "gae": {"config_size": gae_roofline(nat, w["num_steps"], w["num_envs"]),
+                         "traffic_source": traffic_src, "traffic_note": traffic_note, "csrc_hash": csrc_hash()},
+            "gae": {"config_size": gae_roofline(nat, w["num_steps"], trainer.N),
+                    "config_size_scan": gae_roofline(nat, w["num_steps"], trainer.N, mode=native.GAE_SCAN),
                     "hbm_sweep": [gae_roofline(nat, 24, 1 << 20, 20), gae_roofline(nat, 48, 1 << 22, 10)],
                     "bound": "hbm", "peak_GBps": HBM_PEAK_GBPS, "bytes_per_env_step": 24},
         }
@@ -256,6 +359,7 @@ def main():
         out = None
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
+        parallel.shutdown_native_comm()
         torch.distributed.destroy_process_group()
     if out is not None:
         # RCCL writes a version banner through C stdio: flush it first so that the JSON is the last line

@@ -144,8 +144,9 @@ _SIGNATURES = {
     "catppo_policy_act_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
                                        _vp]),
     "catppo_value_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, C.c_int, _vp]),
-    "catppo_ppo_gather_rng": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i32,
-                                        _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_ppo_gather_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32,
+                                       _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "catppo_rms_moments_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rollout_store_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _i64, _vp]),
     "catppo_rms_update_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "catppo_rms_normalize_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp, _f32, _vp, _i64, _vp]),
@@ -549,12 +550,22 @@ class Native:
         self._ok(self.lib.catppo_value_ex(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(value),
                                           self._dt(value), self._stream()))
 
-    def ppo_gather_rng(self, shape, b_obs, b_actions, b_logprobs, b_advantages, b_returns_n, b_values_n, st, epoch,
-                       total, M, x_g, act_g, scal_g, adv_part_g, inds_out=None):
-        self._ok(self.lib.catppo_ppo_gather_rng(
+    def ppo_gather_ex(self, shape, b_obs, b_actions, b_logprobs, b_advantages, b_returns_n, b_values_n, total, M, x_g,
+                      act_g, scal_g, adv_part_g, inds=None, st=None, epoch=0, inds_out=None):
+        """one gather launch for a whole epoch; the permutation is ``inds`` (int64 [total]) or, with ``st``, the
+        keyed on-device bijection of (seed, iteration, epoch)"""
+        if inds is not None:
+            _chk(inds, torch.int64, "inds")
+        _chk(adv_part_g, torch.float64, "adv_part_g")
+        self._ok(self.lib.catppo_ppo_gather_ex(
             self.h, C.byref(shape), _p(b_obs), _p(b_actions), _p(b_logprobs), _p(b_advantages),
-            self._dt(b_advantages), _p(b_returns_n), _p(b_values_n), _p(st), int(epoch), int(total), int(M), _p(x_g),
-            _p(act_g), _p(scal_g), _p(adv_part_g), _p(inds_out), self._stream()))
+            self._dt(b_advantages), _p(b_returns_n), _p(b_values_n), _p(inds), None if inds is not None else _p(st),
+            int(epoch), int(total), int(M), _p(x_g), _p(act_g), _p(scal_g), _p(adv_part_g), _p(inds_out),
+            self._stream()))
+
+    def rms_moments_ex(self, x, n_rows, dim, ldx, sums):
+        self._ok(self.lib.catppo_rms_moments_ex(self.h, _p(x), self._dt(x), int(n_rows), int(dim), int(ldx),
+                                                _p(_chk(sums, torch.float64, "sums")), self._stream()))
 
     def rollout_store_ex(self, reward, dones, time_outs, rewards_t, dones_t1, true_dones_t1):
         self._ok(self.lib.catppo_rollout_store_ex(self.h, _p(reward), _p(dones), _p(time_outs), _p(rewards_t),

@@ -8,7 +8,9 @@ its rollout buffers, its CaT per-env statistics and its GAE; the exchange points
     * advantage mean / std    SUM   2 fp64 per minibatch
 
 The last three make N ranks reproduce ONE process on the union of the shards; the
-helpers are device agnostic (gloo on CPU in the tests, RCCL on the GPUs).
+helpers are device agnostic: on the GPUs they call RCCL directly through libcatppo's C ABI (catppo_comm_init /
+catppo_allreduce, see init_native_comm) - torch.distributed is only the rendezvous that ships the 128-byte unique id -
+and on CPU tensors (the gloo tests) they fall back to torch.distributed.
 """
 from __future__ import annotations
 
@@ -18,6 +20,42 @@ import torch
 import torch.distributed as dist
 
 _FORCE = os.environ.get("CATPPO_FORCE_DIST", "0") == "1"
+#: libcatppo context whose RCCL communicator carries the device-side exchange points (None: torch.distributed does)
+_native = None
+
+
+def init_native_comm(nat, group=None) -> bool:
+    """Create libcatppo's own RCCL communicator (catppo_comm_init) for the ranks of the initialised
+    torch.distributed world: rank 0 makes the unique id, the launcher's process group only ships its 128 bytes.
+    Afterwards every device-tensor exchange point below is a catppo_allreduce / catppo_broadcast on the caller's
+    HIP stream - capturable in a hipGraph, no torch.distributed on the data path.  CATPPO_NATIVE_COMM=0 keeps
+    torch.distributed (RCCL through PyTorch) instead."""
+    global _native
+    if _native is not None:
+        return True
+    if not active(group) or os.environ.get("CATPPO_NATIVE_COMM", "1") == "0":
+        return False
+    box = [nat.comm_unique_id() if rank(group) == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    nat.comm_init(rank(group), world_size(group), box[0])
+    _native = nat
+    return True
+
+
+def shutdown_native_comm():
+    global _native
+    if _native is not None:
+        _native.comm_destroy()
+        _native = None
+
+
+def native_comm_active() -> bool:
+    return _native is not None
+
+
+def _use_native(t: torch.Tensor, group) -> bool:
+    return _native is not None and t.is_cuda and group in (None, dist.group.WORLD) and t.is_contiguous() and \
+        t.dtype in (torch.float32, torch.float64, torch.float16)
 
 
 def world_size(group=None) -> int:
@@ -45,19 +83,28 @@ def shard_slice(n_total: int, r: int, w: int) -> slice:
 
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     if active(group):
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if _use_native(t, group):
+            _native.allreduce(t, 0)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
 def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
     if active(group):
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        if _use_native(t, group):
+            _native.allreduce(t, 1)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return t
 
 
 def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     if active(group):
-        dist.broadcast(t, src=src, group=group)
+        if _use_native(t, group):
+            _native.broadcast(t, src)
+        else:
+            dist.broadcast(t, src=src, group=group)
     return t
 
 

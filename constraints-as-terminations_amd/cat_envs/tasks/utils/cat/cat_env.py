@@ -215,6 +215,7 @@ class CaTEnv:
         self.reset_terminated = torch.zeros_like(self.reset_buf)
         self.reset_time_outs = torch.zeros_like(self.reset_buf)
         self.obs_buf = {"policy": self.sim.view("obs")}
+        self._rstep = None
         self.load_managers()
 
     # gym-style plumbing ---------------------------------------------------------------------
@@ -274,6 +275,62 @@ class CaTEnv:
             self._reset_idx(self.reset_buf)
         # -- observations (:144)
         return self.obs_buf, self.reward_buf, dones, self.reset_time_outs, self.extras
+
+    # fused path ------------------------------------------------------------------------------------
+    def can_step_into(self, obs_dim_ok: bool = True) -> bool:
+        """``step_into`` is available: constraints configured with describable terms, mask-based resets"""
+        cm = getattr(self, "constraint_manager", None)
+        return (cm is not None and not self.exact_reset_sync and obs_dim_ok and self.obs_dim <= 512
+                and cm.can_fuse_rollout(native.get(self.device)))
+
+    def step_into(self, action: torch.Tensor, sink):
+        """``step`` with everything after the simulator update fused into two launches (catppo_rollout_pre /
+        catppo_rollout_post), including the consumer's part: ``sink`` (see ``cleanrl.ppo.RolloutSink``) names the
+        rollout-buffer rows of this step and the observation normaliser, so rewards / dones / time-outs and the
+        normalised next observation are written where PPO wants them.  Same return tuple as ``step``."""
+        from cat_envs import parallel
+        nat = native.get(self.device)
+        cm = self.constraint_manager
+        self._sim_step_counter += self.cfg.decimation
+        self.sim.step()
+        self.common_step_counter += 1
+        st = self._rstep
+        if st is None:
+            st = self._rstep = native.RolloutStep()
+            am = self.action_manager
+            st.N, st.A, st.D = self.num_envs, self.act_dim, self.obs_dim
+            st.action, st.prev_action = am._action.data_ptr(), am._prev_action.data_ptr()
+            st.episode_length, st.max_episode_length = self.episode_length_buf.data_ptr(), self.max_episode_length
+            hr, rw = self.sim.view("hard_reset"), self.sim.view("reward")
+            st.hard_reset, st.hard_reset_stride = hr.data_ptr(), hr.stride(0)
+            st.reward_src, st.reward_stride = rw.data_ptr(), rw.stride(0)
+            st.time_outs, st.terminated = self.reset_time_outs.data_ptr(), self.reset_terminated.data_ptr()
+            st.reset, st.reward, st.dones = self.reset_buf.data_ptr(), self.reward_buf.data_ptr(), self._dones.data_ptr()
+            st.zero_action_on_reset = 1
+            obs = self.sim.view("obs")
+            st.obs_raw, st.obs_ld = obs.data_ptr(), obs.stride(0)
+            self._xchg = nat.rollout_xchg_new(cm.cat._p_cstr.shape[1], self.obs_dim)
+            st.xchg = self._xchg.data_ptr()
+            self._xchg_views = nat.rollout_xchg_views(self._xchg, cm.cat._p_cstr.shape[1], self.obs_dim)
+        action = action if (action.dtype == torch.float32 and action.is_contiguous()) else action.float().contiguous()
+        st.action_in = action.data_ptr()
+        cm.fill_rollout_step(st)
+        sink.fill(st)
+        nat.rollout_pre(st)
+        group = cm.dist_group
+        if group is not None and parallel.active(group):
+            colmax, sums = self._xchg_views
+            parallel.allreduce_max_(colmax, group)      # CaT column maxima: exact, masks stay bit-exact
+            parallel.allreduce_sum_(sums, group)        # observation moments (fp64)
+        nat.rollout_post(st)
+        # curriculum AFTER the CaT step, like _reset_idx (host scalars: the new max_p travels with the next step's
+        # launch; the reference runs it whenever some env resets - with thousands of envs that is every step)
+        self.curriculum_manager.compute(env_ids=self.reset_buf)
+        log = dict(cm.latest_log())
+        log.update(self.curriculum_manager.reset(None))
+        self.extras["log"] = log
+        self.extras["log_packed"] = cm.log_packed
+        return self.obs_buf, self.reward_buf, self._dones, self.reset_time_outs, self.extras
 
     def _reset_idx(self, env_ids: Sequence[int] | torch.Tensor):
         """reference: cat_env.py:149-200.  ``env_ids`` may be a bool mask (sync-free path)."""

@@ -223,15 +223,7 @@ class ConstraintManager(ManagerBase):
             out = self._log_ring[self._log_pos]      # "no env selected" copies the previous slot (in-kernel)
             nat.cat_reset(self._ep_viol, self._ep_prob, self._env.episode_length_buf, mask, out,
                           prev=self._log_ring[prev])
-            if self._log_views is None:
-                self._log_views = []
-                for r in range(self.LOG_RING):
-                    d = {}
-                    for t, key in enumerate(self._term_names):
-                        d[f"Episode_Constraint_violation/{key}"] = self._log_ring[r, 2 * t]
-                        d[f"Episode_Constraint_probability/{key}"] = self._log_ring[r, 2 * t + 1]
-                    self._log_views.append(d)
-            extras = dict(self._log_views[self._log_pos])
+            extras = self.latest_log()
         for term_cfg in self._class_term_cfgs:
             term_cfg.func.reset(env_ids=env_ids)
         return extras
@@ -379,6 +371,51 @@ class ConstraintManager(ManagerBase):
                          self._cstr_prob_buf, self._ep_viol, self._ep_prob, **args)
         cat._p_first = False
         return self._cstr_prob_buf
+
+    # ------------------------------------------------------------------ fused rollout step (catppo_rollout_pre/_post)
+    def can_fuse_rollout(self, nat) -> bool:
+        """the manager's part of an env step can run inside the two-launch fused rollout step: every term has a
+        descriptor (``describe``) and the config fits the kernel's tables"""
+        if not self._term_names:
+            return False
+        if not self._bound:
+            self._bind(nat)
+        return bool(self._fused) and len(self._term_cfgs) <= 16
+
+    def fill_rollout_step(self, st) -> None:
+        """write the manager's buffers / parameters of THIS step into a ``native.RolloutStep`` and advance the log
+        ring (compute() + reset(reset_mask) of the unfused path)."""
+        cat = self.cat
+        descs, forces, H, B, command = self._describe_terms()
+        self._dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
+        st.K, st.n_terms = cat._p_cstr.shape[1], len(self._term_cfgs)
+        st.desc = C.cast(descs, C.c_void_p)
+        st.forces = forces.data_ptr() if forces is not None else None
+        st.forces_env_stride = forces.stride(0) if forces is not None else 0
+        st.H, st.B = int(H), int(B)
+        st.command = command.data_ptr() if command is not None else None
+        st.command_ld = command.stride(0) if command is not None else 0
+        st.cstr = cat._p_cstr.data_ptr()
+        st.term_off, st.term_dp = C.cast(self._term_off, C.c_void_p), C.cast(self._dp, C.c_void_p)
+        st.min_p, st.tau, st.one_minus_tau = native.f32(cat.min_p), native.f32(cat.tau), native.f32(1.0 - cat.tau)
+        st.first_call = int(bool(cat._p_first))
+        st.rm, st.cstr_prob = cat._p_rm.data_ptr(), self._cstr_prob_buf.data_ptr()
+        st.ep_viol, st.ep_prob, st.probs = self._ep_viol.data_ptr(), self._ep_prob.data_ptr(), cat._p_probs.data_ptr()
+        prev, self._log_pos = self._log_pos, (self._log_pos + 1) % self.LOG_RING
+        st.log_prev, st.log_out = self._log_ring[prev].data_ptr(), self._log_ring[self._log_pos].data_ptr()
+        cat._p_first = False
+
+    def latest_log(self) -> Dict[str, torch.Tensor]:
+        """the dict ``reset()`` would have returned for the ring slot written last"""
+        if self._log_views is None:
+            self._log_views = []
+            for r in range(self.LOG_RING):
+                d = {}
+                for t, key in enumerate(self._term_names):
+                    d[f"Episode_Constraint_violation/{key}"] = self._log_ring[r, 2 * t]
+                    d[f"Episode_Constraint_probability/{key}"] = self._log_ring[r, 2 * t + 1]
+                self._log_views.append(d)
+        return dict(self._log_views[self._log_pos])
 
     @property
     def max_p(self) -> Dict[str, torch.Tensor]:

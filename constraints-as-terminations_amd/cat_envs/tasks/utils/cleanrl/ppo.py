@@ -8,11 +8,17 @@ for step (rollout bookkeeping :201-230, GAE with float dones and a separate time
 value losses, global-norm clip, Adam, linear lr anneal :294-354); every tensor operation of it
 runs in libcatppo.so (hand-written HIP, see include/catppo.h):
 
-    rollout step   catppo_rms_update + catppo_rms_normalize   (writes obs[step+1] in place)
-                   catppo_policy_act                          (writes actions/logprobs/values[step])
-                   env.step -> catppo_cat_terms + catppo_cat_step
+    iteration      catppo_iter_begin                          (iteration counter, lr schedule: device state)
+    rollout step   catppo_policy_act_rng                      (3 GEMM launches + head: actions/logprobs/values[step];
+                                                               Philox action noise inside the head kernel)
+                   env.step_into -> catppo_rollout_pre/_post  (terms, CaT, resets, buffer rows, obs normaliser:
+                                                               2 launches; a foreign env takes the unfused calls)
     after rollout  catppo_value, catppo_gae, 2x (catppo_rms_update + catppo_rms_normalize)
-    minibatch      catppo_ppo_minibatch_grad  [RCCL all-reduce of the flat gradient]  catppo_clip_adam
+    epoch          catppo_ppo_gather_ex                       (keyed on-device permutation, no index array)
+    minibatch      catppo_ppo_minibatch_grad_packed  [catppo_allreduce: RCCL SUM of the flat gradient]
+                   catppo_clip_adam_dev                       (lr / step count from the device state)
+    [KL-adaptive]  catppo_kl_mean [catppo_allreduce] catppo_kl_adaptive_lr   after every epoch, no host sync
+The update phase can be replayed from a hipGraph (``graph_update``).
 
 There is no host synchronisation inside an iteration (the reference syncs once per
 constraint term per env step and once per minibatch); diagnostics accumulate on the device
@@ -52,7 +58,7 @@ class RunningMeanStd(nn.Module):
         return max(1, self.running_mean.numel())
 
     def forward(self, obs: torch.Tensor, update: bool = True) -> torch.Tensor:
-        x = obs if obs.dtype == torch.float32 else obs.float()
+        x = obs if obs.dtype in (torch.float32, torch.float16) else obs.float()
         rows = x.reshape(-1, self.dim)
         if rows.stride(-1) != 1:
             rows = rows.contiguous()
@@ -71,12 +77,17 @@ class RunningMeanStd(nn.Module):
         if group is not None and parallel.active(group):
             if not hasattr(self, "_sums"):
                 self._sums = torch.zeros(2 * d, dtype=torch.float64, device=rows.device)
-            nat.rms_moments(rows, n, d, rows.stride(0), self._sums)
+                self._n_global = {}
+            nat.rms_moments_ex(rows, n, d, rows.stride(0), self._sums)
             parallel.global_moment_sums(self._sums, group)
-            n_total = n * parallel.world_size(group)                  # equal shards
-            nat.rms_merge(self._sums, n_total, d, self.running_mean, self.running_var, self.count)
+            # true global row count (shards may differ by one env): exchanged once per batch size, not assumed
+            if n not in self._n_global:
+                cnt = torch.tensor([float(n)], dtype=torch.float64, device=rows.device)
+                parallel.allreduce_sum_(cnt, group)
+                self._n_global[n] = float(cnt.item())
+            nat.rms_merge(self._sums, self._n_global[n], d, self.running_mean, self.running_var, self.count)
         else:
-            nat.rms_update(rows, n, d, rows.stride(0), self.running_mean, self.running_var, self.count)
+            nat.rms_update_ex(rows, n, d, rows.stride(0), self.running_mean, self.running_var, self.count)
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
         """Chan merge of externally computed batch moments (reference ppo.py:33-45).  Not on the training path -
@@ -94,8 +105,8 @@ class RunningMeanStd(nn.Module):
         if update:
             self._update_rows(rows)
         n, d = rows.shape
-        native.get(rows.device).rms_normalize(rows, n, d, rows.stride(0), self.running_mean, self.running_var,
-                                              self.epsilon, out, out.stride(0))
+        native.get(rows.device).rms_normalize_ex(rows, n, d, rows.stride(0), self.running_mean, self.running_var,
+                                                 self.epsilon, out, out.stride(0))
 
 
 def update_mean_var_count_from_moments(mean, var, count, batch_mean, batch_var, batch_count):
@@ -263,6 +274,28 @@ def _make_writer(ppo_cfg, run_path):
     raise AssertionError("logger type not found")
 
 
+class RolloutSink:
+    """Where an env's fused step (``step_into``) delivers this rollout step: the rollout-buffer rows
+    rewards[step] / dones[step+1] / true_dones[step+1], and the observation normaliser whose statistics are
+    updated with the raw next observation and whose output lands in obs[step+1]."""
+
+    def __init__(self, trainer: "PPOTrainer"):
+        self.t = trainer
+        self.step = 0
+        rms = trainer.agent.obs_rms
+        self._rms = (rms.running_mean.data_ptr(), rms.running_var.data_ptr(), rms.count.data_ptr(),
+                     native.f32(rms.epsilon))
+
+    def fill(self, st):
+        t, k = self.t, self.step
+        st.rewards_t, st.dones_t1 = t.rewards[k].data_ptr(), t.dones[k + 1].data_ptr()
+        st.true_dones_t1 = t.true_dones[k + 1].data_ptr()
+        st.plane_dtype = native.F16 if t.plane_dtype == torch.float16 else native.F32
+        st.obs_mean, st.obs_var, st.obs_count, st.obs_eps = self._rms
+        st.obs_rows_total = t.n_envs_global
+        st.obs_out, st.obs_out_ld = t.obs[k + 1].data_ptr(), t.Dp
+
+
 class PPOTrainer:
     """State of one ``PPO()`` run; ``run_iteration`` is one pass of the hot path."""
 
@@ -283,30 +316,58 @@ class PPOTrainer:
             envs, hidden=hidden, mlp_precision=str(getattr(c, "mlp_precision", "fp32"))).to(self.device)
         a = self.agent
         self.D, self.A, self.Dp = a.obs_dim, a.act_dim, a.layout.obs_pad
+        self.rng = str(getattr(c, "rng", "device"))
+        if self.rng not in ("device", "torch"):
+            raise ValueError(f"rng must be 'device' or 'torch', got {self.rng!r}")
+        rd = str(getattr(c, "rollout_dtype", "fp32"))
+        if rd not in ("fp32", "fp16"):
+            raise ValueError(f"rollout_dtype must be 'fp32' or 'fp16', got {rd!r}")
+        self.plane_dtype = torch.float16 if rd == "fp16" else torch.float32
+        self.gae_mode = str(getattr(c, "gae_mode", "serial"))
+        sched = getattr(c, "lr_schedule", None)
+        if sched is None:
+            sched = "linear" if c.anneal_lr else "fixed"
+        if sched not in ("linear", "fixed", "adaptive"):
+            raise ValueError(f"lr_schedule must be None, 'linear', 'fixed' or 'adaptive', got {sched!r}")
+        self.lr_schedule = sched
+        self.n_envs_global = float(self.N)
         if parallel.active():
+            parallel.init_native_comm(self.nat)                 # RCCL under the C ABI (catppo_comm_init)
             parallel.broadcast_(a.flat, src=0)                  # replicas start identical (cf. skrl ppo.py:126-131)
             a.obs_rms.dist_group = a.value_rms.dist_group = torch.distributed.group.WORLD
             cm = getattr(envs.unwrapped, "constraint_manager", None)
             if cm is not None and getattr(c, "dist_exact", True):
                 cm.dist_group = torch.distributed.group.WORLD
+            cnt = torch.tensor([float(self.N)], dtype=torch.float64, device=self.device)
+            parallel.allreduce_sum_(cnt)
+            self.n_envs_global = float(cnt.item())              # shards may differ by one env
         cm = getattr(envs.unwrapped, "constraint_manager", None)
         if cm is not None and hasattr(cm, "ensure_log_ring"):
             cm.ensure_log_ring(self.T + 2)      # the per-step episode logs are read after the rollout
         n_flat = a.layout.n_flat
         dev, T, N = self.device, self.T, self.N
         z = lambda *s, **k: torch.zeros(*s, device=dev, **k)
+        pz = lambda *s: torch.zeros(*s, device=dev, dtype=self.plane_dtype)
         self.grad, self.exp_avg, self.exp_avg_sq = z(n_flat), z(n_flat), z(n_flat)
         self.adam_step = 0
+        # device-resident iteration state: lr, Adam step count, RNG counters (catppo_iter_state)
+        self.state = self.nat.iter_state_new(int(getattr(c, "seed", 0)) * 1000003 + 977 * self.rank + 1,
+                                             float(c.learning_rate))
+        self.kl_buf = z(1)
         # time-major rollout buffers; slot T holds the bootstrap observation / dones (reference keeps them in
-        # next_obs / next_done / next_true_done)
+        # next_obs / next_done / next_true_done).  The six (T,N) planes GAE touches are fp32 or fp16.
         self.obs = z(T + 1, N, self.Dp)
         self.actions = z(T, N, self.A)
-        self.logprobs, self.rewards, self.values = z(T, N), z(T, N), z(T, N)
-        self.dones, self.true_dones = z(T + 1, N), z(T + 1, N)
-        self.advantages, self.returns = z(T, N), z(T, N)
+        self.logprobs = z(T, N)
+        self.rewards, self.values = pz(T, N), pz(T, N)
+        self.dones, self.true_dones = pz(T + 1, N), pz(T + 1, N)
+        self.advantages, self.returns = pz(T, N), pz(T, N)
         self.values_n, self.returns_n = z(T, N), z(T, N)
-        self.next_value = z(N)
-        self.noise = z(T, N, self.A)
+        self.next_value = pz(N)
+        self.noise = z(T, N, self.A) if self.rng == "torch" else None
+        self.record_noise = False        # device rng: keep the noise / permutations used (parity tests replay them)
+        self.noise_rec = None
+        self.perm_rec = None
         self.diag = z(8)
         self.adv_stats = z(2)
         self.hp = native.PpoHparams(float(c.clip_coef), float(c.ent_coef), float(c.vf_coef), int(bool(c.norm_adv)),
@@ -314,10 +375,44 @@ class PPOTrainer:
         self.nat.mlp_reserve(a.shape, max(min(self.mb, self.batch), N))
         self.iteration = 0
         self.global_step = 0
+        # fused env step (two launches) when the env offers it
+        env_u = envs.unwrapped
+        self.sink = None
+        if bool(getattr(c, "fused_rollout", True)) and hasattr(env_u, "step_into") and \
+                getattr(env_u, "can_step_into", lambda: False)() and os.environ.get("CATPPO_FUSED_ROLLOUT", "1") != "0":
+            self.sink = RolloutSink(self)
+        # hipGraph replay of the update phase
+        g = getattr(c, "graph_update", None)
+        env_g = os.environ.get("CATPPO_GRAPH_UPDATE")
+        if env_g is not None:
+            g = env_g == "1"
+        if g is None:
+            g = min(self.mb, self.batch) <= 4096
+        dist_on_torch = parallel.active() and not parallel.native_comm_active()
+        self.graph_update = bool(g) and self.rng == "device" and not dist_on_torch
+        self._graph_id = None
+        self.graph_nodes = 0
+        self.stream = torch.cuda.Stream(device=dev) if self.graph_update else None
         # first observation (ppo.py:186-189)
         first = envs.reset()[0]["policy"]
         a.obs_rms.normalize_into(self._rows(first), self.obs[0])
-        self.phase_ms = {}
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(dev))
+        self.time_phases = False
+        self._phase_events = []
+
+    def phase_summary(self, reset: bool = True):
+        """mean device milliseconds per iteration of the three phases (needs ``time_phases = True``); synchronises"""
+        torch.cuda.synchronize()
+        n = max(len(self._phase_events), 1)
+        out = {"rollout_ms": 0.0, "gae_and_normalisers_ms": 0.0, "update_ms": 0.0, "iterations": len(self._phase_events)}
+        for e in self._phase_events:
+            out["rollout_ms"] += e[0].elapsed_time(e[1]) / n
+            out["gae_and_normalisers_ms"] += e[1].elapsed_time(e[2]) / n
+            out["update_ms"] += e[2].elapsed_time(e[3]) / n
+        if reset:
+            self._phase_events = []
+        return out
 
     @staticmethod
     def _rows(x):
@@ -329,22 +424,35 @@ class PPOTrainer:
     def rollout(self, eps_fn=None):
         c, a, nat, T, N = self.cfg, self.agent, self.nat, self.T, self.N
         ep_infos = []
-        if eps_fn is None:
+        if eps_fn is None and self.rng == "torch":
             self.noise.normal_()                                 # all N(0,1) draws of the iteration at once
+        if self.record_noise and self.noise_rec is None:
+            self.noise_rec = torch.zeros(T, N, self.A, device=self.device)
+        env_u = self.envs.unwrapped
         for step in range(T):
             self.global_step += N * self.world
-            eps = self.noise[step] if eps_fn is None else eps_fn(step)
-            nat.policy_act(a.shape, a.flat, self.obs[step], N, eps, self.actions[step], self.logprobs[step],
-                           self.values[step])
-            next_obs, reward, next_done, timeouts, info = self.envs.step(self.actions[step])
-            if (reward.dtype == torch.float32 and next_done.dtype == torch.float32 and timeouts.dtype == torch.bool
-                    and reward.is_contiguous() and next_done.is_contiguous() and timeouts.is_contiguous()):
-                nat.rollout_store(reward, next_done, timeouts, self.rewards[step], self.dones[step + 1],
-                                  self.true_dones[step + 1])
-            else:                                                # foreign env: dtype conversions in the copies
-                self.rewards[step].copy_(reward)
-                self.dones[step + 1].copy_(next_done)
-                self.true_dones[step + 1].copy_(timeouts)
+            if eps_fn is not None or self.rng == "torch":
+                eps = self.noise[step] if eps_fn is None else eps_fn(step)
+                nat.policy_act_ex(a.shape, a.flat, self.obs[step], N, eps, self.actions[step], self.logprobs[step],
+                                  self.values[step])
+            else:                                                # Philox noise inside the head kernel
+                nat.policy_act_rng(a.shape, a.flat, self.obs[step], N, self.state, step, self.actions[step],
+                                   self.logprobs[step], self.values[step],
+                                   eps_out=self.noise_rec[step] if self.record_noise else None)
+            if self.sink is not None:
+                self.sink.step = step
+                next_obs, reward, next_done, timeouts, info = env_u.step_into(self.actions[step], self.sink)
+            else:
+                next_obs, reward, next_done, timeouts, info = self.envs.step(self.actions[step])
+                if (reward.dtype == torch.float32 and next_done.dtype == torch.float32 and timeouts.dtype == torch.bool
+                        and reward.is_contiguous() and next_done.is_contiguous() and timeouts.is_contiguous()):
+                    nat.rollout_store_ex(reward, next_done, timeouts, self.rewards[step], self.dones[step + 1],
+                                         self.true_dones[step + 1])
+                else:                                            # foreign env: dtype conversions in the copies
+                    self.rewards[step].copy_(reward)
+                    self.dones[step + 1].copy_(next_done)
+                    self.true_dones[step + 1].copy_(timeouts)
+                a.obs_rms.normalize_into(self._rows(next_obs["policy"]), self.obs[step + 1])
             if "episode" in info:
                 ep_infos.append(info["episode"])
             elif "log" in info:
@@ -355,7 +463,6 @@ class PPOTrainer:
                     extra = {k: v for k, v in info["log"].items() if not isinstance(v, torch.Tensor)}
                     ep_infos.append((packed[0], packed[1], extra))
             info["true_dones"] = timeouts
-            a.obs_rms.normalize_into(self._rows(next_obs["policy"]), self.obs[step + 1])
             if "time_outs" in info:
                 if info["time_outs"].any():
                     print("time outs", info["time_outs"].sum())
@@ -365,15 +472,39 @@ class PPOTrainer:
     # ------------------------------------------------------------------ GAE + normalisers (:251-288)
     def compute_returns(self):
         c, a, nat, T, N = self.cfg, self.agent, self.nat, self.T, self.N
-        nat.value(a.shape, a.flat, self.obs[T], N, self.next_value)
-        nat.gae(self.rewards, self.values, self.dones[:T], self.true_dones[:T], self.next_value, self.dones[T],
+        nat.value_ex(a.shape, a.flat, self.obs[T], N, self.next_value)
+        args = (self.rewards, self.values, self.dones[:T], self.true_dones[:T], self.next_value, self.dones[T],
                 self.true_dones[T], c.gamma, c.gae_lambda, self.advantages, self.returns)
+        if self.plane_dtype == torch.float16:
+            nat.gae_f16(*args)
+        elif self.gae_mode == "scan":
+            nat.gae_mode(native.GAE_SCAN, *args)
+        else:
+            nat.gae(*args)
         # value_rms is updated with the values and then, a second time, with the returns (:287-288)
         a.value_rms.normalize_into(self.values.view(-1, 1), self.values_n.view(-1, 1))
         a.value_rms.normalize_into(self.returns.view(-1, 1), self.returns_n.view(-1, 1))
 
     # ------------------------------------------------------------------ update (:294-354)
-    def update(self, perm_fn=None):
+    def _update_buffers(self):
+        if not hasattr(self, "_x_g"):
+            # packed epoch buffers: one gather launch per epoch, minibatch k = contiguous slice k
+            B, M = self.batch, min(self.mb, self.batch)
+            n_mb = (B + M - 1) // M
+            self._parts = (M + self.nat.GATHER_ROWS - 1) // self.nat.GATHER_ROWS
+            self._x_g = torch.empty(B, self.Dp, device=self.device)
+            self._act_g = torch.empty(B, self.A, device=self.device)
+            self._scal_g = torch.empty(4 * B, device=self.device)
+            self._advp_g = torch.empty(n_mb * self._parts * 2, dtype=torch.float64, device=self.device)
+            E = int(self.cfg.updates_epochs)
+            self._adv_mom = torch.zeros(E * n_mb, 3, dtype=torch.float64, device=self.device)
+            self._adv_stats_all = torch.zeros(E * n_mb, 2, device=self.device)
+            self._perm_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
+
+    def _update_body(self, perms):
+        """the launches of one update phase (E epochs x minibatches).  ``perms``: list of index tensors (injected /
+        torch.randperm) or None = keyed on-device permutation.  Contains no host synchronisation, no allocation and
+        only library calls (+ RCCL through the C ABI), so it can be captured into a hipGraph."""
         c, a, nat = self.cfg, self.agent, self.nat
         B, M = self.batch, min(self.mb, self.batch)
         b_obs = self.obs[:self.T].view(B, self.Dp)
@@ -381,32 +512,26 @@ class PPOTrainer:
         b_logp, b_adv = self.logprobs.view(-1), self.advantages.view(-1)
         b_ret, b_val = self.returns_n.view(-1), self.values_n.view(-1)
         vmean, vvar = a.value_rms.running_mean, a.value_rms.running_var
-        self.diag.zero_()
         E = int(c.updates_epochs)
         n_mb = (B + M - 1) // M
         exact_adv = parallel.active() and bool(c.norm_adv) and getattr(c, "dist_exact", True)
-        perms = [torch.randperm(B, device=self.device) if perm_fn is None else perm_fn(e) for e in range(E)]
-        if exact_adv:
-            # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318): the moments of every
-            # minibatch of the iteration in one launch per epoch, ONE all-reduce, one finishing launch
-            if not hasattr(self, "_adv_mom") or self._adv_mom.shape[0] != E * n_mb:
-                self._adv_mom = torch.zeros(E * n_mb, 3, dtype=torch.float64, device=self.device)
-                self._adv_stats_all = torch.zeros(E * n_mb, 2, device=self.device)
-            for e in range(E):
-                nat.adv_moments(b_adv, perms[e], M, self._adv_mom[e * n_mb:(e + 1) * n_mb])
-            parallel.allreduce_sum_(self._adv_mom)
-            nat.adv_stats(self._adv_mom, E * n_mb, self._adv_stats_all)
         self.hp.adv_stats_external = int(exact_adv)
-        if not hasattr(self, "_x_g"):
-            # packed epoch buffers: one gather launch per epoch, minibatch k = contiguous slice k
-            self._parts = (M + nat.GATHER_ROWS - 1) // nat.GATHER_ROWS
-            self._x_g = torch.empty(B, self.Dp, device=self.device)
-            self._act_g = torch.empty(B, self.A, device=self.device)
-            self._scal_g = torch.empty(4 * B, device=self.device)
-            self._advp_g = torch.empty(n_mb * self._parts * 2, dtype=torch.float64, device=self.device)
         for epoch in range(E):
-            nat.ppo_gather(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, perms[epoch], M, self._x_g,
-                           self._act_g, self._scal_g, self._advp_g)
+            rec = self.perm_rec[epoch] if self.perm_rec is not None else None
+            if exact_adv and perms is None and rec is None:
+                rec = self._perm_dev                              # the moments below need the permutation
+            nat.ppo_gather_ex(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, B, M, self._x_g, self._act_g,
+                              self._scal_g, self._advp_g, inds=None if perms is None else perms[epoch],
+                              st=self.state, epoch=epoch, inds_out=rec if perms is None else None)
+            if exact_adv:
+                # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318): the moments of every
+                # minibatch of the epoch in one launch, ONE all-reduce, one finishing launch
+                if b_adv.dtype != torch.float32:
+                    raise NotImplementedError("dist_exact advantage statistics with fp16 rollout planes")
+                mom = self._adv_mom[epoch * n_mb:(epoch + 1) * n_mb]
+                nat.adv_moments(b_adv, perms[epoch] if perms is not None else rec, M, mom)
+                parallel.allreduce_sum_(mom)
+                nat.adv_stats(mom, n_mb, self._adv_stats_all[epoch * n_mb:(epoch + 1) * n_mb])
             for k, start in enumerate(range(0, B, M)):
                 m = min(M, B - start)
                 self.hp.inv_global_batch = 1.0 / (m * self.world)
@@ -415,22 +540,81 @@ class PPOTrainer:
                                               self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
                                               vmean, vvar, adv_stats, self.grad, self.diag)
                 parallel.allreduce_sum_(self.grad)              # RCCL SUM of the flat gradient over xGMI
-                self.adam_step += 1
-                nat.clip_adam(a.flat, self.grad, self.exp_avg, self.exp_avg_sq, a.layout.n_flat,
-                              c.max_grad_norm, self.lr, 0.9, 0.999, 1e-5, self.adam_step)
+                nat.clip_adam_dev(a.flat, self.grad, self.exp_avg, self.exp_avg_sq, a.layout.n_flat,
+                                  c.max_grad_norm, 0.9, 0.999, 1e-5, self.state)
+            if self.lr_schedule == "adaptive":
+                # KL-adaptive learning rate after every epoch (skrl/ppo.py:558-567), entirely on the device
+                nat.kl_mean(self.state, self.diag, self.kl_buf)
+                parallel.allreduce_sum_(self.kl_buf)            # per-rank values SUM to the global mean KL
+                nat.kl_adaptive_lr(self.state, self.kl_buf, float(getattr(c, "kl_threshold", 0.01)))
+        return E * n_mb
+
+    def update(self, perm_fn=None):
+        c = self.cfg
+        B = self.batch
+        E = int(c.updates_epochs)
+        self._update_buffers()
+        self.diag.zero_()
+        if self.record_noise and self.perm_rec is None:
+            self.perm_rec = torch.zeros(E, B, dtype=torch.int64, device=self.device)
+        perms = None
+        if perm_fn is not None:
+            perms = [perm_fn(e) for e in range(E)]
+        elif self.rng == "torch":
+            perms = [torch.randperm(B, device=self.device) for e in range(E)]
+        if self.graph_update and perms is None and not self.record_noise:
+            if self._graph_id is not None:
+                try:
+                    self.nat.graph_launch(self._graph_id)
+                    self.adam_step += self._graph_steps
+                    return
+                except RuntimeError:                             # workspace grew: the graph was dropped
+                    self._graph_id = None
+            self.nat.graph_begin()
+            try:
+                self._graph_steps = self._update_body(None)
+            finally:
+                self._graph_id, self.graph_nodes = self.nat.graph_end()
+            self.nat.graph_launch(self._graph_id)
+            self.adam_step += self._graph_steps
+            return
+        self.adam_step += self._update_body(perms)
 
     # ------------------------------------------------------------------ one iteration
     def run_iteration(self, eps_fn=None, perm_fn=None, log: bool = True):
+        if self.stream is None:
+            return self._run_iteration(eps_fn, perm_fn, log)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):                     # graph capture needs a non-default stream
+            out = self._run_iteration(eps_fn, perm_fn, log)
+        cur.wait_stream(self.stream)
+        return out
+
+    def _run_iteration(self, eps_fn=None, perm_fn=None, log: bool = True):
         c = self.cfg
         self.iteration += 1
         it = self.iteration
         self.lr = float(c.learning_rate)
-        if c.anneal_lr:
+        sched = {"fixed": native.LR_FIXED, "linear": native.LR_LINEAR, "adaptive": native.LR_KEEP}[self.lr_schedule]
+        if self.lr_schedule == "linear":
             frac = 1.0 - (it - 1.0) / c.num_iterations
-            self.lr = frac * c.learning_rate
+            self.lr = frac * c.learning_rate                     # host mirror of the device-side schedule (logging)
+        self.nat.iter_begin(self.state, float(c.learning_rate), int(c.num_iterations), sched)
+        ev = None
+        if self.time_phases:                                     # HIP events on the stream the launches go to
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
         ep_infos = self.rollout(eps_fn)
+        if ev:
+            ev[1].record()
         self.compute_returns()
+        if ev:
+            ev[2].record()
         self.update(perm_fn)
+        if ev:
+            ev[3].record()
+            self._phase_events.append(ev)
         # slot T becomes slot 0 of the next rollout (next_obs / next_done / next_true_done carry over)
         self.obs[0].copy_(self.obs[self.T])
         self.dones[0].copy_(self.dones[self.T])
@@ -441,6 +625,8 @@ class PPOTrainer:
             parallel.allreduce_sum_(self.diag)
             self.diag[7] /= self.world
         d = self.diag.cpu().numpy()                              # the one host sync of the iteration
+        if self.lr_schedule == "adaptive":
+            self.lr = float(self.nat.iter_state_read(self.state).lr)
         n_upd = max(d[7], 1.0)
         stats = {"mean_pg_loss": d[0] / n_upd, "mean_v_loss": d[1] / n_upd, "mean_entropy_loss": d[2] / n_upd,
                  "mean_surrogate_loss": d[3] / n_upd, "approx_kl": d[4] / n_upd, "old_approx_kl": d[5] / n_upd,

@@ -83,6 +83,13 @@ extern "C" int catppo_reserve(catppo_ctx* ctx, uint64_t bytes) {
                        hipGetErrorString(e));
   }
   if (ctx->ws) (void)hipFree(ctx->ws);
+  // captured graphs hold pointers into the old block: drop them (catppo_graph_launch then fails and the caller
+  // captures again)
+  for (auto& g : ctx->graphs)
+    if (g) {
+      (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
   ctx->ws = p;
   ctx->ws_bytes = bytes;
   (void)hipSetDevice(cur);

@@ -1040,23 +1040,25 @@ extern "C" int catppo_ppo_gather(catppo_ctx* ctx, const catppo_mlp_shape* shape,
   return CATPPO_OK;
 }
 
-extern "C" int catppo_ppo_gather_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs,
-                                     const float* b_actions, const float* b_logprobs, const void* b_advantages,
-                                     int adv_dtype, const float* b_returns_n, const float* b_values_n,
-                                     const catppo_iter_state* state, int32_t epoch, int64_t total, int64_t M,
-                                     float* x_g, float* act_g, float* scal_g, double* adv_part_g, int64_t* inds_out,
-                                     void* stream) {
+extern "C" int catppo_ppo_gather_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs,
+                                    const float* b_actions, const float* b_logprobs, const void* b_advantages,
+                                    int adv_dtype, const float* b_returns_n, const float* b_values_n,
+                                    const int64_t* inds, const catppo_iter_state* state, int32_t epoch, int64_t total,
+                                    int64_t M, float* x_g, float* act_g, float* scal_g, double* adv_part_g,
+                                    int64_t* inds_out, void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   catppo_mlp_layout L;
   CATPPO_CHECK_ARG(ctx, shape && catppo_mlp_layout_of(shape, &L) == CATPPO_OK);
-  CATPPO_CHECK_ARG(ctx, b_obs && b_actions && b_logprobs && b_advantages && b_returns_n && b_values_n && state);
+  CATPPO_CHECK_ARG(ctx, b_obs && b_actions && b_logprobs && b_advantages && b_returns_n && b_values_n);
+  CATPPO_CHECK_ARG(ctx, (inds != nullptr) != (state != nullptr));    // exactly one source of the permutation
+  if (inds != nullptr) state = nullptr;
   CATPPO_CHECK_ARG(ctx, adv_dtype == CATPPO_F32 || adv_dtype == CATPPO_F16);
   CATPPO_CHECK_ARG(ctx, x_g && act_g && scal_g && adv_part_g && total >= 1 && total < (int64_t(1) << 31) && M >= 1);
   const int64_t n_mb = cdiv64(total, M);
   CATPPO_CHECK_ARG(ctx, n_mb <= 65535);
   hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), (unsigned)n_mb), dim3(256), 0,
                      static_cast<hipStream_t>(stream), b_obs, b_actions, b_logprobs,
-                     static_cast<const float*>(b_advantages), b_returns_n, b_values_n, (const int64_t*)nullptr, total,
+                     static_cast<const float*>(b_advantages), b_returns_n, b_values_n, inds, total,
                      M, L.obs_pad, shape->act_dim, x_g, act_g, scal_g, adv_part_g, state, (int)epoch,
                      (int)(adv_dtype == CATPPO_F16), inds_out);
   CATPPO_CHECK_LAUNCH(ctx);

@@ -327,6 +327,27 @@ extern "C" int catppo_value_bootstrap(catppo_ctx* ctx, float* rewards, const flo
 }
 
 // ---- fp16 inputs (BASELINE config 5: fp16 rollout planes) ------------------------------------------------------
+extern "C" int catppo_rms_moments_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
+                                     double* sums, void* stream) {
+  if (x_dtype == CATPPO_F32) return catppo_rms_moments(ctx, static_cast<const float*>(x), N, D, ldx, sums, stream);
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16 && x && sums && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int Dc = D < kThreads ? D : kThreads;
+  const int rows_per_block = (kThreads / Dc) * 16;
+  int nblk = (int)cdiv64(N, rows_per_block);
+  if (nblk > 128) nblk = 128;
+  WsCarver ws(ctx);
+  double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
+  CATPPO_NEED_WS(ctx, partial);
+  hipLaunchKernelGGL(rms_moments_partial<_Float16>, dim3(nblk), dim3(kThreads), 0, s, static_cast<const _Float16*>(x), N,
+                     D, ldx, rows_per_block, partial);
+  CATPPO_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(rms_moments_final, dim3(1), dim3(kThreads), 0, s, partial, nblk, D, sums);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
 extern "C" int catppo_rms_update_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
                                     float* mean, float* var, float* count, void* stream) {
   if (x_dtype == CATPPO_F32) return catppo_rms_update(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, count, stream);

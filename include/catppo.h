@@ -412,23 +412,26 @@ int catppo_policy_act_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const f
 int catppo_value_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
                     void* value, int value_dtype, void* stream);
 
-/* catppo_ppo_gather whose permutation is computed on the fly (replaces torch.randperm, cleanrl/ppo.py:295):
- * sample j of the epoch reads row P(j), P = a keyed bijection of [0,total) (4-round Feistel network on the next
- * power of four with cycle walking, round keys from Philox(seed; iteration, epoch)).  No index array, no sort.
- * inds_out ([total] int64, may be NULL) receives P for parity tests.  adv_dtype: element type of b_advantages
- * (CATPPO_F16 for fp16 rollout planes; widened on the way into the packed buffers). */
-int catppo_ppo_gather_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs, const float* b_actions,
-                          const float* b_logprobs, const void* b_advantages, int adv_dtype, const float* b_returns_n,
-                          const float* b_values_n, const catppo_iter_state* state, int32_t epoch, int64_t total,
-                          int64_t M, float* x_g, float* act_g, float* scal_g, double* adv_part_g, int64_t* inds_out,
-                          void* stream);
+/* catppo_ppo_gather with (a) either an index array `inds` (state == NULL) or a permutation computed on the fly
+ * (inds == NULL; replaces torch.randperm, cleanrl/ppo.py:295): sample j of the epoch reads row P(j), P = a keyed
+ * bijection of [0,total) (6-round Feistel network on the next power of four with cycle walking, round keys from
+ * Philox(seed; iteration, epoch)) - no index array, no sort; inds_out ([total] int64, may be NULL) receives P for
+ * parity tests - and (b) adv_dtype: element type of b_advantages (CATPPO_F16 for fp16 rollout planes; widened on
+ * the way into the packed buffers). */
+int catppo_ppo_gather_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs, const float* b_actions,
+                         const float* b_logprobs, const void* b_advantages, int adv_dtype, const float* b_returns_n,
+                         const float* b_values_n, const int64_t* inds, const catppo_iter_state* state, int32_t epoch,
+                         int64_t total, int64_t M, float* x_g, float* act_g, float* scal_g, double* adv_part_g,
+                         int64_t* inds_out, void* stream);
 
 /* ---- fp16 rollout planes (BASELINE config 5) ------------------------------------------------------------------
  * catppo_rollout_store_ex: catppo_rollout_store with the three destination rows in `dtype`.
- * catppo_rms_update_ex / catppo_rms_normalize_ex: RunningMeanStd over an input of `x_dtype` (widened exactly;
+ * catppo_rms_moments_ex / _update_ex / _normalize_ex: RunningMeanStd over an input of `x_dtype` (widened exactly;
  * statistics, state and output stay fp32). */
 int catppo_rollout_store_ex(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
                             void* rewards_t, void* dones_t1, void* true_dones_t1, int dtype, int64_t N, void* stream);
+int catppo_rms_moments_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx, double* sums,
+                          void* stream);
 int catppo_rms_update_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx, float* mean,
                          float* var, float* count, void* stream);
 int catppo_rms_normalize_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,

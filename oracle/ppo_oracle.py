@@ -295,9 +295,13 @@ class PPOOracle:
                        clip_vloss=True, anneal_lr=True)
 
     def __init__(self, env, num_envs, obs_dim, act_dim, cfg=None, hidden=(512, 256, 128), seed=0,
-                 agent: AgentOracle | None = None):
+                 agent: AgentOracle | None = None, rollout_dtype: str = "fp32"):
         self.cfg = dict(self.DEFAULT_CFG)
         self.cfg.update(cfg or {})
+        # "fp16": restatement of the build's fp16 rollout planes (BASELINE config 5, not a reference code path):
+        # rewards / values / dones / true_dones / next_value are rounded to IEEE half (RNE) when stored, GAE runs in
+        # fp32 on the widened values, advantages and returns (= fl32(A + v)) are rounded to half when stored
+        self.q = (lambda t: t.half().float()) if rollout_dtype == "fp16" else (lambda t: t)
         self.env, self.N, self.D, self.A = env, num_envs, obs_dim, act_dim
         self.agent = agent or AgentOracle(obs_dim, act_dim, hidden, seed)
         self.params = [p.requires_grad_(True) for p in self.agent.parameters()]
@@ -324,25 +328,28 @@ class PPOOracle:
             frac = 1.0 - (self.iteration - 1.0) / c["num_iterations"]
             self.opt.param_groups[0]["lr"] = frac * c["learning_rate"]
         t0 = time.perf_counter()
+        q = self.q
         for step in range(T):
-            self.obs[step], self.dones[step] = self.next_obs, self.next_done
+            self.obs[step], self.dones[step] = self.next_obs, q(self.next_done)
             self.true_dones[step] = self.next_true_done
             with torch.no_grad():
                 eps = None if eps_fn is None else eps_fn(step)
                 given = None if actions_fn is None else actions_fn(step)
                 action, logprob, _, value = self.agent.get_action_and_value(self.next_obs, action=given, eps=eps)
-            self.values[step], self.actions[step], self.logprobs[step] = value.flatten(), action, logprob
+            self.values[step], self.actions[step], self.logprobs[step] = q(value.flatten()), action, logprob
             te = time.perf_counter()
-            nobs, self.rewards[step], nd, timeouts, _info = self.env.step(action)
+            nobs, rew, nd, timeouts, _info = self.env.step(action)
+            self.rewards[step] = q(rew)
             self.timers["env"] += time.perf_counter() - te
             self.next_done = nd.to(torch.float)
             self.next_obs = self.agent.obs_rms(nobs["policy"])
             self.next_true_done = timeouts.float()
         t1 = time.perf_counter()
         with torch.no_grad():
-            nv = self.agent.get_value(self.next_obs).reshape(1, -1)
+            nv = q(self.agent.get_value(self.next_obs).reshape(1, -1))
             adv, returns = gae(self.rewards, self.values, self.dones, self.true_dones, nv[0],
-                               self.next_done, self.next_true_done, c["gamma"], c["gae_lambda"])
+                               q(self.next_done), self.next_true_done, c["gamma"], c["gae_lambda"])
+            adv, returns = q(adv), q(returns)
         t2 = time.perf_counter()
         b_obs, b_logp = self.obs.reshape(-1, self.D), self.logprobs.reshape(-1)
         b_act, b_adv = self.actions.reshape(-1, self.A), adv.reshape(-1)

@@ -1,5 +1,5 @@
-"""Wall time of the phases of one CaT-PPO iteration (cfg2 shapes): host enqueue time (Python + ctypes, before the
-sync) and device-complete time.  python tools/phase_times.py [--workload cfg2|reference] [--iters 10]"""
+"""Device time of the phases of one CaT-PPO iteration (HIP events on the trainer's stream) and the host time the
+iteration takes to enqueue.  python tools/phase_times.py [--workload cfg2|reference|cfg3_shard|...] [--iters 10]"""
 import argparse
 import json
 import os
@@ -27,23 +27,18 @@ def main():
     for _ in range(3):
         trainer.run_iteration(log=False)
     torch.cuda.synchronize()
-    acc = {}
+    trainer.time_phases = True
+    t0 = time.perf_counter()
     for _ in range(a.iters):
-        for name, fn in (("rollout", trainer.rollout), ("compute_returns", trainer.compute_returns),
-                         ("update", trainer.update)):
-            t0 = time.perf_counter()
-            fn()
-            t1 = time.perf_counter()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            e = acc.setdefault(name, [0.0, 0.0])
-            e[0] += t1 - t0
-            e[1] += t2 - t0
-        trainer.obs[0].copy_(trainer.obs[trainer.T])
-        trainer.dones[0].copy_(trainer.dones[trainer.T])
-        trainer.true_dones[0].copy_(trainer.true_dones[trainer.T])
-    print(json.dumps({k: {"host_enqueue_ms": 1e3 * v[0] / a.iters, "device_done_ms": 1e3 * v[1] / a.iters}
-                      for k, v in acc.items()}, indent=1))
+        trainer.run_iteration(log=False)
+    t1 = time.perf_counter()
+    out = trainer.phase_summary()
+    t2 = time.perf_counter()
+    out["host_enqueue_ms_per_iteration"] = 1e3 * (t1 - t0) / a.iters
+    out["wall_ms_per_iteration"] = 1e3 * (t2 - t0) / a.iters
+    out["fused_rollout"] = trainer.sink is not None
+    out["graph_update"] = trainer.graph_update
+    print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":

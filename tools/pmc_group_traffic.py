@@ -7,7 +7,10 @@ Calibration in the same run: gae_scan<1> at 4096x24 reads 4 planes + 3 rows = 1,
 python tools/pmc_group_traffic.py gpurun_out/pmc_FETCH_SIZE.csv gpurun_out/pmc_WRITE_SIZE.csv > profiles/rN_pmc_traffic.json"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "seg_reduce_kernel")
 
@@ -31,7 +34,9 @@ def per_launch(path):
 
 f, n, fd, fg = per_launch(sys.argv[1])
 w, _, wd, wg = per_launch(sys.argv[2])
-out = {"kernel_group": "catppo_ppo_minibatch_grad_packed", "minibatches_profiled": n,
+import bench  # noqa: E402  (csrc_hash: bench.py reports traffic only from a summary measured on the current kernels)
+
+out = {"kernel_group": "catppo_ppo_minibatch_grad_packed", "minibatches_profiled": n, "csrc_hash": bench.csrc_hash(),
        "FETCH_SIZE_KiB_per_launch_raw": f, "WRITE_SIZE_KiB_per_launch": w,
        "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
        "correction": "FETCH_SIZE x2 (gfx950, wide coalesced loads), WRITE_SIZE x1, KiB -> bytes",

@@ -6,11 +6,11 @@
 # Counter passes are separate runs with nothing but --pmc (gpurun refuses --pmc mixed with trace domains).
 set -u
 WL=${1:-cfg2}
-TAG=${2:-r1}
+TAG=${2:-r2}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $PWD/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $PWD/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"
 run_pass() {   # name, rocprof args...
   local name=$1; shift
   local dir=/tmp/prof_$name
