@@ -218,10 +218,11 @@ def f32(x: float) -> float:
     return C.c_float(x).value
 
 
-def shape_of(obs_dim: int, act_dim: int, hidden, mfma_bf16: bool = False) -> MlpShape:
+def shape_of(obs_dim: int, act_dim: int, hidden, mfma_bf16=False) -> MlpShape:
+    """mfma_bf16: False/0 = fp32 MFMA, True/1 = bf16 operands, 2 = split-bf16 (bf16x3)"""
     s = MlpShape()
     s.obs_dim, s.act_dim, s.n_hidden = int(obs_dim), int(act_dim), len(hidden)
-    s.mfma_bf16 = int(bool(mfma_bf16))
+    s.mfma_bf16 = int(mfma_bf16)
     for i, h in enumerate(hidden):
         s.hidden[i] = int(h)
     return s

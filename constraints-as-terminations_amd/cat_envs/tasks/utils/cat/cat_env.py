@@ -16,6 +16,7 @@ No host synchronisation happens inside ``step``: resets are handled with masks
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import types
 from collections.abc import Sequence
@@ -101,6 +102,7 @@ class SyntheticSolo12Sim:
         put("hard_reset", (rand(S, N, 1) < 0.01).float())
         put("obs", randn(S, N, obs_dim))
         self.stream = st
+        self._slabs = list(st.unbind(0))
         self.cur = torch.zeros(N, F, device=self.device)       # persistent "simulator state" buffers
         self.cursor = -1
         self.default_joint_pos = dq.repeat(N, 1).contiguous()
@@ -130,7 +132,7 @@ class SyntheticSolo12Sim:
 
     def step(self):
         self.cursor = (self.cursor + 1) % self.S
-        self.cur.copy_(self.stream[self.cursor])               # "scene.update": one contiguous slab
+        self.cur.copy_(self._slabs[self.cursor])               # "scene.update": one contiguous slab
 
 
 class _ActionManager:
@@ -164,14 +166,16 @@ class _CurriculumManager:
         self._env = env
         items = cfg.items() if isinstance(cfg, dict) else (cfg.__dict__.items() if cfg is not None else [])
         self._terms = [(n, t) for n, t in items if t is not None]
+        self._keyed = [(f"Curriculum/{n}", t) for n, t in self._terms]
         self._state = {}
 
     def compute(self, env_ids=None):
-        for name, term in self._terms:
-            self._state[name] = term.func(self._env, env_ids, **term.params)
+        env, state = self._env, self._state
+        for key, term in self._keyed:
+            state[key] = term.func(env, env_ids, **term.params)
 
     def reset(self, env_ids=None):
-        return {f"Curriculum/{n}": v for n, v in self._state.items() if isinstance(v, (int, float))}
+        return {k: v for k, v in self._state.items() if isinstance(v, (int, float))}
 
 
 class CaTEnv:
@@ -216,6 +220,7 @@ class CaTEnv:
         self.reset_time_outs = torch.zeros_like(self.reset_buf)
         self.obs_buf = {"policy": self.sim.view("obs")}
         self._rstep = None
+        self._nat = None
         self.load_managers()
 
     # gym-style plumbing ---------------------------------------------------------------------
@@ -287,15 +292,19 @@ class CaTEnv:
         """``step`` with everything after the simulator update fused into two launches (catppo_rollout_pre /
         catppo_rollout_post), including the consumer's part: ``sink`` (see ``cleanrl.ppo.RolloutSink``) names the
         rollout-buffer rows of this step and the observation normaliser, so rewards / dones / time-outs and the
-        normalised next observation are written where PPO wants them.  Same return tuple as ``step``."""
-        from cat_envs import parallel
-        nat = native.get(self.device)
+        normalised next observation are written where PPO wants them.  Same return tuple as ``step``; ``extras["log"]``
+        is the manager's view dict of the ring slot written by this step, the curriculum scalars ride in
+        ``extras["log_host"]``."""
+        nat = self._nat
         cm = self.constraint_manager
         self._sim_step_counter += self.cfg.decimation
         self.sim.step()
         self.common_step_counter += 1
         st = self._rstep
         if st is None:
+            from cat_envs import parallel
+            self._parallel = parallel
+            nat = self._nat = native.get(self.device)
             st = self._rstep = native.RolloutStep()
             am = self.action_manager
             st.N, st.A, st.D = self.num_envs, self.act_dim, self.obs_dim
@@ -312,25 +321,33 @@ class CaTEnv:
             self._xchg = nat.rollout_xchg_new(cm.cat._p_cstr.shape[1], self.obs_dim)
             st.xchg = self._xchg.data_ptr()
             self._xchg_views = nat.rollout_xchg_views(self._xchg, cm.cat._p_cstr.shape[1], self.obs_dim)
-        action = action if (action.dtype == torch.float32 and action.is_contiguous()) else action.float().contiguous()
+            self._rstep_ref = C.byref(st)
+        if action.dtype != torch.float32 or not action.is_contiguous():
+            action = action.float().contiguous()
         st.action_in = action.data_ptr()
         cm.fill_rollout_step(st)
         sink.fill(st)
-        nat.rollout_pre(st)
+        lib, h, stream = nat.lib, nat.h, nat._stream()
+        rc = lib.catppo_rollout_pre(h, self._rstep_ref, stream)
+        if rc:
+            nat._ok(rc)
         group = cm.dist_group
-        if group is not None and parallel.active(group):
+        if group is not None and self._parallel.active(group):
             colmax, sums = self._xchg_views
-            parallel.allreduce_max_(colmax, group)      # CaT column maxima: exact, masks stay bit-exact
-            parallel.allreduce_sum_(sums, group)        # observation moments (fp64)
-        nat.rollout_post(st)
+            self._parallel.allreduce_max_(colmax, group)      # CaT column maxima: exact, masks stay bit-exact
+            self._parallel.allreduce_sum_(sums, group)        # observation moments (fp64)
+        rc = lib.catppo_rollout_post(h, self._rstep_ref, stream)
+        if rc:
+            nat._ok(rc)
         # curriculum AFTER the CaT step, like _reset_idx (host scalars: the new max_p travels with the next step's
         # launch; the reference runs it whenever some env resets - with thousands of envs that is every step)
-        self.curriculum_manager.compute(env_ids=self.reset_buf)
-        log = dict(cm.latest_log())
-        log.update(self.curriculum_manager.reset(None))
-        self.extras["log"] = log
-        self.extras["log_packed"] = cm.log_packed
-        return self.obs_buf, self.reward_buf, self._dones, self.reset_time_outs, self.extras
+        cur = self.curriculum_manager
+        cur.compute(env_ids=self.reset_buf)
+        ex = self.extras
+        ex["log"] = cm.latest_log(copy=False)
+        ex["log_host"] = cur._state
+        ex["log_packed"] = cm.log_packed
+        return self.obs_buf, self.reward_buf, self._dones, self.reset_time_outs, ex
 
     def _reset_idx(self, env_ids: Sequence[int] | torch.Tensor):
         """reference: cat_env.py:149-200.  ``env_ids`` may be a bool mask (sync-free path)."""

@@ -140,6 +140,7 @@ class ConstraintManager(ManagerBase):
         self.cat = CaT(tau, min_p)
         self._device = torch.device(env.device)
         self._term_names: List[str] = []
+        self._term_index: Dict[str, int] = {}
         self._term_cfgs: List[ConstraintTermCfg] = []
         self._class_term_cfgs: List[ConstraintTermCfg] = []
         super().__init__(cfg, env)          # -> _prepare_terms()
@@ -153,11 +154,15 @@ class ConstraintManager(ManagerBase):
         self._cstr_prob_buf = torch.zeros(n, dtype=torch.float, device=self._device)
         self._log_ring = torch.zeros(self.LOG_RING, 2 * max(nt, 1), device=self._device)
         self._log_views = None
+        self._log_keys = self._log_rows = None
         self._log_pos = 0
         self._bound = False
         self._fused = False
         self._desc_cache = None
         self._desc_key = None
+        self._desc_dirty, self._desc_age = False, 0
+        self._dp = None
+        self._rs_table = self._rs_struct = self._rs_ring = None
         self.term_cache = True
         self._widths: List[int] = []
         self._term_off = None
@@ -235,16 +240,19 @@ class ConstraintManager(ManagerBase):
             return
         ring = torch.zeros(n_slots, self._log_ring.shape[1], device=self._device)
         ring[:self.LOG_RING] = self._log_ring
-        self.LOG_RING, self._log_ring, self._log_views = n_slots, ring, None
+        self.LOG_RING, self._log_ring, self._log_views, self._log_rows = n_slots, ring, None, None
 
     @property
     def log_packed(self):
         """(keys, tensor[2*n_terms]) of the latest reset() - lets a trainer stack one tensor per
         step instead of 2*n_terms scalars."""
-        keys = []
-        for key in self._term_names:
-            keys += [f"Episode_Constraint_violation/{key}", f"Episode_Constraint_probability/{key}"]
-        return keys, self._log_ring[self._log_pos]
+        if self._log_keys is None:
+            self._log_keys = []
+            for key in self._term_names:
+                self._log_keys += [f"Episode_Constraint_violation/{key}", f"Episode_Constraint_probability/{key}"]
+        if self._log_rows is None or len(self._log_rows) != self.LOG_RING:
+            self._log_rows = list(self._log_ring.unbind(0))
+        return self._log_keys, self._log_rows[self._log_pos]
 
     # ------------------------------------------------------------------ compute
     def _bind(self, nat):
@@ -287,8 +295,15 @@ class ConstraintManager(ManagerBase):
         # re-evaluates the term inputs on every compute().
         persistent = bool(getattr(env, "persistent_state_buffers", False))
         cache = self._desc_cache if (self.term_cache and persistent) else None
-        if cache is not None and self._desc_key == self._params_key():
-            return cache
+        if cache is not None:
+            # parameter snapshot: checked whenever set_term_cfg saw a changed object, and every 64th step to catch
+            # in-place edits of term_cfg.params that never went through set_term_cfg
+            self._desc_age += 1
+            if not self._desc_dirty and self._desc_age < 64:
+                return cache
+            self._desc_dirty, self._desc_age = False, 0
+            if self._desc_key == self._params_key():
+                return cache
         rows, forces, command, H, B, keep = [], None, None, 1, 1, []
         for cfg in self._term_cfgs:
             d = cfg.func.describe(env, **cfg.params)
@@ -384,28 +399,40 @@ class ConstraintManager(ManagerBase):
 
     def fill_rollout_step(self, st) -> None:
         """write the manager's buffers / parameters of THIS step into a ``native.RolloutStep`` and advance the log
-        ring (compute() + reset(reset_mask) of the unfused path)."""
+        ring (compute() + reset(reset_mask) of the unfused path).  Runs once per env step on the host: everything
+        that does not change from step to step is written only when the descriptor table is (re)built."""
         cat = self.cat
-        descs, forces, H, B, command = self._describe_terms()
-        self._dp = (C.c_float * len(self._term_cfgs))(*[native.f32(c.max_p - cat.min_p) for c in self._term_cfgs])
-        st.K, st.n_terms = cat._p_cstr.shape[1], len(self._term_cfgs)
-        st.desc = C.cast(descs, C.c_void_p)
-        st.forces = forces.data_ptr() if forces is not None else None
-        st.forces_env_stride = forces.stride(0) if forces is not None else 0
-        st.H, st.B = int(H), int(B)
-        st.command = command.data_ptr() if command is not None else None
-        st.command_ld = command.stride(0) if command is not None else 0
-        st.cstr = cat._p_cstr.data_ptr()
-        st.term_off, st.term_dp = C.cast(self._term_off, C.c_void_p), C.cast(self._dp, C.c_void_p)
-        st.min_p, st.tau, st.one_minus_tau = native.f32(cat.min_p), native.f32(cat.tau), native.f32(1.0 - cat.tau)
-        st.first_call = int(bool(cat._p_first))
-        st.rm, st.cstr_prob = cat._p_rm.data_ptr(), self._cstr_prob_buf.data_ptr()
-        st.ep_viol, st.ep_prob, st.probs = self._ep_viol.data_ptr(), self._ep_prob.data_ptr(), cat._p_probs.data_ptr()
-        prev, self._log_pos = self._log_pos, (self._log_pos + 1) % self.LOG_RING
-        st.log_prev, st.log_out = self._log_ring[prev].data_ptr(), self._log_ring[self._log_pos].data_ptr()
+        table = self._describe_terms()
+        if table is not self._rs_table or st is not self._rs_struct:
+            descs, forces, H, B, command = table
+            self._rs_table, self._rs_struct = table, st
+            self._dp = (C.c_float * len(self._term_cfgs))()
+            st.K, st.n_terms = cat._p_cstr.shape[1], len(self._term_cfgs)
+            st.desc = C.cast(descs, C.c_void_p)
+            st.forces = forces.data_ptr() if forces is not None else None
+            st.forces_env_stride = forces.stride(0) if forces is not None else 0
+            st.H, st.B = int(H), int(B)
+            st.command = command.data_ptr() if command is not None else None
+            st.command_ld = command.stride(0) if command is not None else 0
+            st.cstr = cat._p_cstr.data_ptr()
+            st.term_off, st.term_dp = C.cast(self._term_off, C.c_void_p), C.cast(self._dp, C.c_void_p)
+            st.min_p, st.tau, st.one_minus_tau = native.f32(cat.min_p), native.f32(cat.tau), native.f32(1.0 - cat.tau)
+            st.rm, st.cstr_prob = cat._p_rm.data_ptr(), self._cstr_prob_buf.data_ptr()
+            st.ep_viol, st.ep_prob = self._ep_viol.data_ptr(), self._ep_prob.data_ptr()
+            st.probs = cat._p_probs.data_ptr()
+            self._rs_ring = (self._log_ring.data_ptr(), self._log_ring.stride(0) * 4, self.LOG_RING)
+        dp, min_p = self._dp, cat.min_p
+        for i, c in enumerate(self._term_cfgs):
+            dp[i] = c.max_p - min_p              # double -> fp32 (RNE) in the assignment: fl32(max_p - min_p)
+        st.first_call = 1 if cat._p_first else 0
+        base, stride, ring = self._rs_ring
+        if ring != self.LOG_RING:                # ring was enlarged
+            self._rs_ring = base, stride, ring = (self._log_ring.data_ptr(), self._log_ring.stride(0) * 4, self.LOG_RING)
+        prev, self._log_pos = self._log_pos, (self._log_pos + 1) % ring
+        st.log_prev, st.log_out = base + prev * stride, base + self._log_pos * stride
         cat._p_first = False
 
-    def latest_log(self) -> Dict[str, torch.Tensor]:
+    def latest_log(self, copy: bool = True) -> Dict[str, torch.Tensor]:
         """the dict ``reset()`` would have returned for the ring slot written last"""
         if self._log_views is None:
             self._log_views = []
@@ -415,7 +442,7 @@ class ConstraintManager(ManagerBase):
                     d[f"Episode_Constraint_violation/{key}"] = self._log_ring[r, 2 * t]
                     d[f"Episode_Constraint_probability/{key}"] = self._log_ring[r, 2 * t + 1]
                 self._log_views.append(d)
-        return dict(self._log_views[self._log_pos])
+        return dict(self._log_views[self._log_pos]) if copy else self._log_views[self._log_pos]
 
     @property
     def max_p(self) -> Dict[str, torch.Tensor]:
@@ -424,20 +451,23 @@ class ConstraintManager(ManagerBase):
 
     # ------------------------------------------------------------------ term cfg access
     def set_term_cfg(self, term_name: str, cfg: ConstraintTermCfg):
-        if term_name not in self._term_names:
+        i = self._term_index.get(term_name)
+        if i is None:
             raise ValueError(f"Constraint term '{term_name}' not found.")
-        i = self._term_names.index(term_name)
         old = self._term_cfgs[i]
         self._term_cfgs[i] = cfg
-        # the curriculum rewrites max_p through here at every reset (max_p travels with every launch); a changed
-        # function / parameter set is caught by the parameter snapshot checked in _describe_terms()
-        if cfg.func is not old.func:
-            self._desc_cache = None
+        # the curriculum rewrites max_p through here at every reset with the SAME cfg object (max_p travels with
+        # every launch); a different object / function / params dict makes _describe_terms() re-check its snapshot
+        if cfg is not old:
+            self._desc_dirty = True
+            if cfg.func is not old.func:
+                self._desc_cache = None
 
     def get_term_cfg(self, term_name: str) -> ConstraintTermCfg:
-        if term_name not in self._term_names:
+        i = self._term_index.get(term_name)
+        if i is None:
             raise ValueError(f"Constraint term '{term_name}' not found.")
-        return self._term_cfgs[self._term_names.index(term_name)]
+        return self._term_cfgs[i]
 
     def _prepare_terms(self):
         cfg_items = self.cfg.items() if isinstance(self.cfg, dict) else self.cfg.__dict__.items()
@@ -451,6 +481,7 @@ class ConstraintManager(ManagerBase):
                 raise TypeError(f"Limit for term '{term_name}' must be float or int. "
                                 f"Received: '{type(term_cfg.max_p)}'.")
             self._resolve_common_term_cfg(term_name, term_cfg, min_argc=1)
+            self._term_index[term_name] = len(self._term_names)
             self._term_names.append(term_name)
             self._term_cfgs.append(term_cfg)
             if isinstance(term_cfg.func, ManagerTermBase):

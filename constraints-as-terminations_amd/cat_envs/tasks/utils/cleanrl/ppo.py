@@ -27,6 +27,7 @@ fp32 buffer each, so the gradient exchange of an env-sharded run is a single all
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 import os
 import time
@@ -38,6 +39,8 @@ import torch.nn as nn
 from cat_envs import native, parallel
 
 DEFAULT_HIDDEN = (512, 256, 128)     # reference Agent (ppo.py:78-95)
+#: arithmetic of the hidden-layer GEMMs -> catppo_mlp_shape.mfma_bf16
+MLP_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -137,8 +140,8 @@ class Agent(nn.Module):
 
     def __init__(self, envs, hidden=DEFAULT_HIDDEN, device=None, mlp_precision: str = "fp32"):
         super().__init__()
-        if mlp_precision not in ("fp32", "bf16"):
-            raise ValueError(f"mlp_precision must be 'fp32' or 'bf16', got {mlp_precision!r}")
+        if mlp_precision not in MLP_PRECISIONS:
+            raise ValueError(f"mlp_precision must be one of {sorted(MLP_PRECISIONS)}, got {mlp_precision!r}")
         self.mlp_precision = mlp_precision
         obs_shape = envs.unwrapped.single_observation_space["policy"].shape
         act_shape = envs.unwrapped.single_action_space.shape
@@ -147,7 +150,7 @@ class Agent(nn.Module):
         if device is None:
             device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         device = torch.device(device)
-        self.shape = native.shape_of(self.obs_dim, self.act_dim, self.hidden, mfma_bf16=mlp_precision == "bf16")
+        self.shape = native.shape_of(self.obs_dim, self.act_dim, self.hidden, mfma_bf16=MLP_PRECISIONS[mlp_precision])
         self.layout = native.layout_of(self.shape)
 
         def mlp(out_dim, out_std):
@@ -277,23 +280,35 @@ def _make_writer(ppo_cfg, run_path):
 class RolloutSink:
     """Where an env's fused step (``step_into``) delivers this rollout step: the rollout-buffer rows
     rewards[step] / dones[step+1] / true_dones[step+1], and the observation normaliser whose statistics are
-    updated with the raw next observation and whose output lands in obs[step+1]."""
+    updated with the raw next observation and whose output lands in obs[step+1].  Addresses are computed from base
+    pointers (no tensor slicing on the per-step host path)."""
 
     def __init__(self, trainer: "PPOTrainer"):
-        self.t = trainer
+        t = self.t = trainer
         self.step = 0
-        rms = trainer.agent.obs_rms
+        rms = t.agent.obs_rms
         self._rms = (rms.running_mean.data_ptr(), rms.running_var.data_ptr(), rms.count.data_ptr(),
                      native.f32(rms.epsilon))
+        isz = t.rewards.element_size()
+        self._row = t.N * isz
+        self._p_rew, self._p_done, self._p_td = t.rewards.data_ptr(), t.dones.data_ptr(), t.true_dones.data_ptr()
+        self._p_obs, self._obs_row = t.obs.data_ptr(), t.N * t.Dp * 4
+        self._dtype = native.F16 if t.plane_dtype == torch.float16 else native.F32
+        self._struct = None
 
     def fill(self, st):
-        t, k = self.t, self.step
-        st.rewards_t, st.dones_t1 = t.rewards[k].data_ptr(), t.dones[k + 1].data_ptr()
-        st.true_dones_t1 = t.true_dones[k + 1].data_ptr()
-        st.plane_dtype = native.F16 if t.plane_dtype == torch.float16 else native.F32
-        st.obs_mean, st.obs_var, st.obs_count, st.obs_eps = self._rms
-        st.obs_rows_total = t.n_envs_global
-        st.obs_out, st.obs_out_ld = t.obs[k + 1].data_ptr(), t.Dp
+        k = self.step
+        if st is not self._struct:               # constants of the run: once per argument block
+            self._struct = st
+            st.plane_dtype = self._dtype
+            st.obs_mean, st.obs_var, st.obs_count, st.obs_eps = self._rms
+            st.obs_rows_total = self.t.n_envs_global
+            st.obs_out_ld = self.t.Dp
+        row = self._row
+        st.rewards_t = self._p_rew + k * row
+        st.dones_t1 = self._p_done + (k + 1) * row
+        st.true_dones_t1 = self._p_td + (k + 1) * row
+        st.obs_out = self._p_obs + (k + 1) * self._obs_row
 
 
 class PPOTrainer:
@@ -364,6 +379,7 @@ class PPOTrainer:
         self.advantages, self.returns = pz(T, N), pz(T, N)
         self.values_n, self.returns_n = z(T, N), z(T, N)
         self.next_value = pz(N)
+        self._act_rows = list(self.actions.unbind(0))
         self.noise = z(T, N, self.A) if self.rng == "torch" else None
         self.record_noise = False        # device rng: keep the noise / permutations used (parity tests replay them)
         self.noise_rec = None
@@ -429,19 +445,32 @@ class PPOTrainer:
         if self.record_noise and self.noise_rec is None:
             self.noise_rec = torch.zeros(T, N, self.A, device=self.device)
         env_u = self.envs.unwrapped
+        # per-step host path: raw addresses instead of tensor slices, the library called directly
+        lib, h, shp = nat.lib, nat.h, C.byref(a.shape)
+        p_flat, p_state = a.flat.data_ptr(), self.state.data_ptr()
+        p_obs, p_act, p_lp, p_val = self.obs.data_ptr(), self.actions.data_ptr(), self.logprobs.data_ptr(), \
+            self.values.data_ptr()
+        s_obs, s_act, s_lp, s_val = N * self.Dp * 4, N * self.A * 4, N * 4, N * self.values.element_size()
+        vdt = native.F16 if self.plane_dtype == torch.float16 else native.F32
+        act_rows = self._act_rows
+        use_rng = eps_fn is None and self.rng != "torch"
         for step in range(T):
             self.global_step += N * self.world
-            if eps_fn is not None or self.rng == "torch":
+            if use_rng:                                          # Philox noise inside the head kernel
+                rc = lib.catppo_policy_act_rng(
+                    h, shp, p_flat, p_obs + step * s_obs, N, p_state, step,
+                    self.noise_rec[step].data_ptr() if self.record_noise else None, p_act + step * s_act,
+                    p_lp + step * s_lp, p_val + step * s_val, vdt, nat._stream())
+            else:
                 eps = self.noise[step] if eps_fn is None else eps_fn(step)
-                nat.policy_act_ex(a.shape, a.flat, self.obs[step], N, eps, self.actions[step], self.logprobs[step],
-                                  self.values[step])
-            else:                                                # Philox noise inside the head kernel
-                nat.policy_act_rng(a.shape, a.flat, self.obs[step], N, self.state, step, self.actions[step],
-                                   self.logprobs[step], self.values[step],
-                                   eps_out=self.noise_rec[step] if self.record_noise else None)
+                rc = lib.catppo_policy_act_ex(h, shp, p_flat, p_obs + step * s_obs, N, eps.data_ptr(), None,
+                                              p_act + step * s_act, p_lp + step * s_lp, p_val + step * s_val, vdt,
+                                              nat._stream())
+            if rc:
+                nat._ok(rc)
             if self.sink is not None:
                 self.sink.step = step
-                next_obs, reward, next_done, timeouts, info = env_u.step_into(self.actions[step], self.sink)
+                next_obs, reward, next_done, timeouts, info = env_u.step_into(act_rows[step], self.sink)
             else:
                 next_obs, reward, next_done, timeouts, info = self.envs.step(self.actions[step])
                 if (reward.dtype == torch.float32 and next_done.dtype == torch.float32 and timeouts.dtype == torch.bool
@@ -460,7 +489,9 @@ class PPOTrainer:
                 if packed is None:
                     ep_infos.append(info["log"])
                 else:                                 # (keys, device tensor) + the host-side scalars of the log
-                    extra = {k: v for k, v in info["log"].items() if not isinstance(v, torch.Tensor)}
+                    host = info.get("log_host")
+                    extra = dict(host) if host is not None else \
+                        {k: v for k, v in info["log"].items() if not isinstance(v, torch.Tensor)}
                     ep_infos.append((packed[0], packed[1], extra))
             info["true_dones"] = timeouts
             if "time_outs" in info:

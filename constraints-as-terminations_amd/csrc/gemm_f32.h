@@ -66,7 +66,7 @@ __device__ __forceinline__ float elu_f(float z) {
 
 // One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
 // (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, bool BF16 = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0>
 __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, const int nwg, const int bz,
                                           float* __restrict__ smem) {
   constexpr int BK = BKT;                      // shadows gemm::BK inside the kernel
@@ -247,7 +247,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
         }
       }
     };
-    if constexpr (!BF16) {
+    if constexpr (PREC == 0) {
 #pragma unroll
       for (int blk = 0; blk < BK / 8; ++blk) {
         float af[TM][4], bf[TN][4];
@@ -265,7 +265,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
       // bf16 operands, fp32 accumulation: the same fp32 LDS images, rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on
       // the way into ONE v_mfma_f32_32x32x16_bf16 per 16 k.  Slot (h, i) of the instruction carries
       // k = 8*(i/4) + 4*h + i%4 for A and B alike, so the contraction is complete and each product exact.
-      static_assert(!BF16 || BK % 16 == 0, "bf16 path consumes 16 k per MFMA");
+      static_assert(PREC == 0 || BK % 16 == 0, "bf16 paths consume 16 k per MFMA");
 #pragma unroll
       for (int kb = 0; kb < BK / 16; ++kb) {
         float a0[TM][4], a1[TM][4], b0[TN][4], b1[TN][4];
@@ -282,6 +282,35 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
         for (int t = 0; t < TN; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) pb[t][q] = (__bf16)b0[t][q], pb[t][4 + q] = (__bf16)b1[t][q];
+        if constexpr (PREC == 2) {
+          // split-bf16 ("bf16x3"): x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits per operand.
+          //   a.b ~= a_hi.b_hi + a_hi.b_lo + a_lo.b_hi        (the dropped a_lo.b_lo term is 2^-16 relative)
+          // three v_mfma_f32_32x32x16_bf16 (3 x 8 passes) replace eight v_mfma_f32_32x32x2_f32 (8 x 16 passes) per
+          // 16 k: 5.3x less matrix-pipe time at ~16-bit operand precision - finer than the TF32 (10-bit) arithmetic the
+          // reference itself enables for these GEMMs (scripts/clean_rl/train.py:86-87).  Small terms first.
+          bf16x8 la[TM], lb[TN];
+#pragma unroll
+          for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              la[t][q] = (__bf16)(a0[t][q] - (float)pa[t][q]);
+              la[t][4 + q] = (__bf16)(a1[t][q] - (float)pa[t][4 + q]);
+            }
+#pragma unroll
+          for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              lb[t][q] = (__bf16)(b0[t][q] - (float)pb[t][q]);
+              lb[t][4 + q] = (__bf16)(b1[t][q] - (float)pb[t][4 + q]);
+            }
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[tm], pb[tn], acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[tm], lb[tn], acc[tm][tn], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -380,10 +409,10 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
   }
 }
 
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, bool BF16 = false>
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT, BF16>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT, PREC>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
 }
 
 // Two independent problems in ONE launch: the first n0 workgroups (in launch order) run problem 0, the rest
@@ -391,16 +420,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
 // CU) together with its data gradient (many short workgroups): the short ones fill the issue slots the long
 // ones leave idle, and one launch boundary disappears.
 template <int BM0, int BN0, bool A_KC0, bool B_KC0, int EPI0, int BM1, int BN1, bool A_KC1, bool B_KC1, int EPI1,
-          bool BF16 = false>
+          int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const Params p0, const Params p1, const int tiles0,
                                                         const int n0, const int tiles1) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < n0) {
-    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0, BK, BF16>(p0, b % tiles0, tiles0, b / tiles0, smem);
+    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0, BK, PREC>(p0, b % tiles0, tiles0, b / tiles0, smem);
   } else {
     const int c = b - n0;
-    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1, BK, BF16>(p1, c % tiles1, tiles1, c / tiles1, smem);
+    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1, BK, PREC>(p1, c % tiles1, tiles1, c / tiles1, smem);
   }
 }
 

@@ -33,6 +33,7 @@ constexpr int kGatherRows = 64;
 int layout_of(const catppo_mlp_shape* s, catppo_mlp_layout* L) {
   if (!s || !L) return CATPPO_E_ARG;
   if (s->obs_dim < 1 || s->act_dim < 1 || s->act_dim >= kMaxA) return CATPPO_E_ARG;  // slot act_dim = critic
+  if (s->mfma_bf16 < 0 || s->mfma_bf16 > 2) return CATPPO_E_ARG;
   if (s->n_hidden < 1 || s->n_hidden > CATPPO_MAX_HIDDEN) return CATPPO_E_ARG;
   for (int l = 0; l < s->n_hidden; ++l)
     if (s->hidden[l] < 64 || s->hidden[l] % 64 != 0 || s->hidden[l] > 4096) return CATPPO_E_ARG;
@@ -133,11 +134,13 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
 
 // ------------------------------------------------------------------------------- GEMM launch
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-void launch_gemm(const Params& p, hipStream_t s, bool bf16) {
+void launch_gemm(const Params& p, hipStream_t s, int prec) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);   // 1-D tile index, see kernel
   constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
-  if (bf16)
-    gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, true><<<grid, dim3(256), lds, s>>>(p);
+  if (prec == 2)
+    gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, 2><<<grid, dim3(256), lds, s>>>(p);
+  else if (prec == 1)
+    gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, 1><<<grid, dim3(256), lds, s>>>(p);
   else
     gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI><<<grid, dim3(256), lds, s>>>(p);
 }
@@ -146,16 +149,16 @@ void launch_gemm(const Params& p, hipStream_t s, bool bf16) {
 // the contraction is long enough to amortise its heavier epilogue and there are >= 1.5 workgroups per
 // CU; the data-gradient form (aux read + store epilogue) is always better with 64x64 tiles.
 template <bool A_KC, bool B_KC, int EPI>
-void launch_gemm_auto(const Params& p, hipStream_t s, bool bf16) {
+void launch_gemm_auto(const Params& p, hipStream_t s, int prec) {
   const int64_t big = (int64_t)((p.I + 127) / 128) * ((p.J + 127) / 128) * p.nets * p.splits;
   const int kc = EPI == gemm::EPI_PARTIAL ? p.kc_per_split : p.Kc;
   // weight gradients pick their split count to fill the chip, so only the shape matters there
   const bool use_big = EPI != gemm::EPI_MUL_DELU && p.I >= 128 && p.J >= 128 && kc >= 256 &&
                        (EPI == gemm::EPI_PARTIAL || big >= 384);
   if (use_big)
-    launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, bf16);
+    launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, prec);
   else
-    launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, bf16);
+    launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, prec);
 }
 
 template <int BM, int BN>
@@ -165,27 +168,30 @@ constexpr int tiles_of(const Params& p) { return ((p.J + BN - 1) / BN) * ((p.I +
 // tiles - measured best inside the pair on MI355X, 350 -> 338 us per minibatch against 64x64 - or 64x64 for
 // layers narrower than 128) of one layer in one launch
 template <int BM0, int BN0, int BM1, int BN1>
-void launch_pair_tiles(const Params& pw, const Params& px, hipStream_t s, bool bf16) {
+void launch_pair_tiles(const Params& pw, const Params& px, hipStream_t s, int prec) {
   const int t0 = tiles_of<BM0, BN0>(pw), n0 = t0 * pw.nets * pw.splits;
   const int t1 = tiles_of<BM1, BN1>(px), n1 = t1 * px.nets * px.splits;
   constexpr size_t lds0 = gemm::smem_bytes<BM0, BN0, false, false>();
   constexpr size_t lds1 = gemm::smem_bytes<BM1, BN1, true, false>();
   constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
-  if (bf16)
-    gemm::gemm_pair_kernel<BM0, BN0, false, false, gemm::EPI_PARTIAL, BM1, BN1, true, false, gemm::EPI_MUL_DELU, true>
+  if (prec == 2)
+    gemm::gemm_pair_kernel<BM0, BN0, false, false, gemm::EPI_PARTIAL, BM1, BN1, true, false, gemm::EPI_MUL_DELU, 2>
+        <<<dim3(n0 + n1), dim3(256), lds, s>>>(pw, px, t0, n0, t1);
+  else if (prec == 1)
+    gemm::gemm_pair_kernel<BM0, BN0, false, false, gemm::EPI_PARTIAL, BM1, BN1, true, false, gemm::EPI_MUL_DELU, 1>
         <<<dim3(n0 + n1), dim3(256), lds, s>>>(pw, px, t0, n0, t1);
   else
     gemm::gemm_pair_kernel<BM0, BN0, false, false, gemm::EPI_PARTIAL, BM1, BN1, true, false, gemm::EPI_MUL_DELU>
         <<<dim3(n0 + n1), dim3(256), lds, s>>>(pw, px, t0, n0, t1);
 }
 
-void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, bool bf16) {
+void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, int prec) {
   const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256;   // launch_gemm_auto's rule for EPI_PARTIAL
   const bool wide = px.J >= 128;
-  if (big && wide) launch_pair_tiles<128, 128, 64, 128>(pw, px, s, bf16);
-  else if (big) launch_pair_tiles<128, 128, 64, 64>(pw, px, s, bf16);
-  else if (wide) launch_pair_tiles<64, 64, 64, 128>(pw, px, s, bf16);
-  else launch_pair_tiles<64, 64, 64, 64>(pw, px, s, bf16);
+  if (big && wide) launch_pair_tiles<128, 128, 64, 128>(pw, px, s, prec);
+  else if (big) launch_pair_tiles<128, 128, 64, 64>(pw, px, s, prec);
+  else if (wide) launch_pair_tiles<64, 64, 64, 128>(pw, px, s, prec);
+  else launch_pair_tiles<64, 64, 64, 64>(pw, px, s, prec);
 }
 
 // hidden-layer forward for `nets` networks starting at net index net0
@@ -208,7 +214,7 @@ void forward_hidden(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, cons
       p.op[n].bias = params + L.off_b[net][l];
       p.op[n].C = w.H[net][l];
     }
-    launch_gemm_auto<true, true, gemm::EPI_BIAS_ELU>(p, s, sh->mfma_bf16 != 0);
+    launch_gemm_auto<true, true, gemm::EPI_BIAS_ELU>(p, s, sh->mfma_bf16);
   }
 }
 
@@ -1158,7 +1164,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   // CATPPO_SIDE_STREAM=1 (measured slower, kept for A/B): the weight gradients are forked to the context's side
   // stream as soon as a layer's dZ exists and joined before returning to the caller's stream order.
   const bool fork = ctx->use_side;
-  const bool bf16 = shape->mfma_bf16 != 0;
+  const int bf16 = shape->mfma_bf16;   // 0 fp32 MFMA, 1 bf16 operands, 2 split-bf16 (bf16x3)
   hipStream_t side = fork ? ctx->side : s;
 #define CATPPO_HIP_OK(call)                                                                          \
   do {                                                                                               \

@@ -262,7 +262,11 @@ typedef struct catppo_mlp_shape {
   int32_t mfma_bf16;                /* 0: fp32-input MFMA (reference numerics, default).  1: the hidden-layer GEMMs
                                        (forward, data gradient, weight gradient) round their operands to bf16
                                        (RNE) and use v_mfma_f32_32x32x16_bf16 with fp32 accumulation; parameters,
-                                       activations, gradients and the optimiser stay fp32 (BASELINE config 5). */
+                                       activations, gradients and the optimiser stay fp32 (BASELINE config 5).
+                                       2: split-bf16 ("bf16x3"): every operand is split x = hi + lo (two bf16 values,
+                                       16 mantissa bits) and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on the bf16
+                                       matrix pipe - meets the fp32 parity tolerances at 5x less matrix-pipe time;
+                                       finer than the TF32 the reference enables (scripts/clean_rl/train.py:86-87). */
 } catppo_mlp_shape;
 
 typedef struct catppo_mlp_layout {

@@ -321,9 +321,12 @@ def unflatten_grad(shape, lay, flat, sd_like):
                                            (45, 12, (512, 256, 128), 1000), (45, 12, (128, 512), 300),
                                            (48, 7, (64,), 100), (33, 15, (64, 128, 64, 128), 70),
                                            (16, 1, (128, 64), 1)])
-def test_policy_act_vs_oracle_and_golden(nat, golden, D, A, hidden, B):
+@pytest.mark.parametrize("prec", [0, 2], ids=["fp32mfma", "bf16x3"])
+def test_policy_act_vs_oracle_and_golden(nat, golden, D, A, hidden, B, prec):
+    """prec 0: fp32-input MFMA.  prec 2: split-bf16 operands (three bf16 MFMAs per product, 16 mantissa bits) held
+    to the SAME fp32 tolerances against the fp32 oracle and the reference Agent's golden outputs."""
     from cat_envs import native
-    shape = native.shape_of(D, A, hidden)
+    shape = native.shape_of(D, A, hidden, mfma_bf16=prec)
     lay = native.layout_of(shape)
     w = S.agent_weights(3, D, A, hidden)
     ag = PO.AgentOracle(D, A, hidden)
@@ -384,10 +387,11 @@ def _minibatch_case(D, A, hidden, Bsz, M, seed):
     (33, 15, (64, 128, 64, 128), 1024, 300, (True, True)),    # deepest (4 hidden layers), widest action (15)
     (16, 1, (128, 64), 512, 65, (True, False)),               # one action dimension, minibatch of 65
 ])
-def test_ppo_minibatch_grad_vs_autograd_oracle(nat, D, A, hidden, Bsz, M, flags):
+@pytest.mark.parametrize("prec", [0, 2], ids=["fp32mfma", "bf16x3"])
+def test_ppo_minibatch_grad_vs_autograd_oracle(nat, D, A, hidden, Bsz, M, flags, prec):
     from cat_envs import native
     norm_adv, clip_vloss = flags
-    shape = native.shape_of(D, A, hidden)
+    shape = native.shape_of(D, A, hidden, mfma_bf16=prec)
     lay = native.layout_of(shape)
     w = S.agent_weights(5, D, A, hidden)
     c = _minibatch_case(D, A, hidden, Bsz, M, 6)

@@ -423,6 +423,19 @@ def test_adaptive_lr_schedule_end_to_end():
     assert lrs[-1] != 3e-4          # 12 epochs with KL far from 0.008 at the start: the schedule moved
 
 
+def test_bf16x3_whole_iteration_at_fp32_tolerances():
+    """mlp_precision='bf16x3' (split-bf16 operands on the bf16 matrix pipe) through a whole cfg2-shaped iteration,
+    against the FP32 oracle at the same tolerances as the fp32-MFMA path (masks bit-exact, values 2e-5, advantages
+    5e-5, parameters 2e-4, all x2 like the other end-to-end tests)."""
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=1024, num_steps=24, minibatch=4096, epochs=3, iters=2,
+                                             hidden=(256, 256, 256), six_terms=True, obs_dim=48,
+                                             agent_overrides={"mlp_precision": "bf16x3"})
+    assert trainer.agent.shape.mfma_bf16 == 2
+    rep = smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+    print(rep)
+
+
 # ------------------------------------------------------------------------------------------ RCCL under the C ABI
 def test_rccl_c_abi_world_of_one_and_graph_capture():
     """catppo_comm_unique_id / _init / catppo_allreduce / _broadcast on a world of size 1 (the only world a one-GPU
