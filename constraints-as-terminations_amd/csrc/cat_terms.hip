@@ -39,7 +39,7 @@ __global__ __launch_bounds__(kThreads) void cat_terms_kernel(TermTable tab, int6
       for (int w = lane; w < rows * W; w += 64) {
         const int e = w / W, j = w - e * W;
         const int64_t env = r0 + e;
-        const float out = eval_term(d, env, j, forces, fstride, H, B, command, cld);
+        const float out = eval_term(d, d.ids, env, j, forces, fstride, H, B, command, cld);
         tile[e * K + col0 + j] = out;
       }
     }

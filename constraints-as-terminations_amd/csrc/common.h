@@ -30,7 +30,9 @@ struct catppo_ctx {
   int comm_rank = 0, comm_world = 0;
   // device-side completion tickets of the "last workgroup folds" kernels (zero between launches)
   unsigned int* tickets = nullptr;   // [kTickets]
-  static constexpr int kTickets = 16;
+  static constexpr int kTickets = 64;
+  static constexpr int kTicketPre = 0;     // rollout_pre: [0] launch-wide + [1..32] per workgroup group
+  static constexpr int kTicketPost = 40;   // rollout_post
   char err[512] = {0};
 };
 

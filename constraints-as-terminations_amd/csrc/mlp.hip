@@ -499,10 +499,10 @@ constexpr int kHeadMaxBlocks = 512;  // = number of weight-gradient partials fol
 //   phase 2 (thread per weight column)  dW4 += G^T . H over the 32 rows of the tile from LDS; accumulators
 //           stay in registers across the tiles of the block => ONE partial per block, no per-wave
 //           reduction rounds
-template <int CPL>
+template <int CPL, int TRS = 0>   // TRS: row-tile override (16 for small minibatches: twice the workgroups)
 __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void head_loss_kernel(const HeadArgs g) {
   constexpr int kHeadWaves = head_waves<CPL>();
-  constexpr int TR = CPL == 8 ? 16 : kHeadRowsPerBlock;
+  constexpr int TR = TRS ? TRS : (CPL == 8 ? 16 : kHeadRowsPerBlock);
   constexpr int kHeadRowsPerWave = TR / kHeadWaves;
   constexpr int HL = CPL * 64;
   constexpr int NT = kHeadWaves * 64;
@@ -1097,7 +1097,10 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
                         const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s) {
   const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
   const int nbg = (int)cdiv64(M, kGatherRows);
-  const int TRh = head_rows(HL);
+  // small minibatches (env-sharded runs: 2048 samples per rank): 16-row tiles double the workgroup count of a launch
+  // that would otherwise occupy a quarter of the CUs
+  const bool small_tiles = HL <= 256 && cdiv64(M, head_rows(HL)) < 128;
+  const int TRh = small_tiles ? 16 : head_rows(HL);
   int nbh = (int)cdiv64(M, TRh);
   // head_loss blocks = weight-gradient partials folded afterwards.  Its LDS tile decides residency: when only one
   // block fits a CU (HL >= 256) a second round of blocks cannot overlap the first, so one block per CU walks
@@ -1141,6 +1144,12 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     g.M = M, g.A = A, g.hp = *hp;
     const int rc = dispatch_cpl(HL, [&](auto cpl) {
       constexpr int CPL = decltype(cpl)::value;
+      if constexpr (CPL <= 4) {
+        if (small_tiles) {
+          head_loss_kernel<CPL, 16><<<dim3(nbh), dim3(head_waves<CPL>() * 64), head_lds, s>>>(g);
+          return;
+        }
+      }
       auto kern = head_loss_kernel<CPL>;
       if (head_lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1192,6 +1201,19 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     if (splits < 1) splits = 1;
     int per = (int)cdiv64(M, splits);
     per = (per + gemm::BK - 1) / gemm::BK * gemm::BK;
+    if (!(out >= 128 && in >= 128 && per >= 256)) {
+      // 64x64 tiles will be used (narrow layer, or a minibatch too small for 256-row contraction chunks): size the
+      // split for ~512 workgroups with at least 128 contraction rows each.  At 2048 samples the old rule cut a
+      // 256x512 layer into 2048 workgroups of 64 rows - four slabs of work between a prologue and a 33 MB partial store.
+      const int t64 = ((out + 63) / 64) * ((in + 63) / 64) * 2;
+      splits = 512 / (t64 > 0 ? t64 : 1);
+      const int max128 = (int)(M / 128);
+      if (splits > max128) splits = max128;
+      if (splits > split_cap(out, in)) splits = split_cap(out, in);
+      if (splits < 1) splits = 1;
+      per = (int)cdiv64(M, splits);
+      per = (per + gemm::BK - 1) / gemm::BK * gemm::BK;
+    }
     splits = (int)cdiv64(M, per);
     pw.splits = splits;
     pw.kc_per_split = per;

@@ -55,20 +55,24 @@ struct PreArgs {
   int64_t obs_ld;
   float* colmax_partial;    // [grid][K]
   double* osum_partial;     // [grid][2D]
+  float* colmax_group;      // [n_groups][K]    second level of the fold tree
+  double* osum_group;       // [n_groups][2D]
   float* x_colmax;          // exchange buffer
   double* x_sums;
-  unsigned int* ticket;
+  unsigned int* ticket;     // [0] = launch-wide ticket, [1 + g] = ticket of workgroup group g
 };
+constexpr int kFoldGroup = 32;    // workgroups per first-level fold
+constexpr int kMaxPreBlocks = 1024;
 
-__device__ __forceinline__ bool last_block_arrives(unsigned int* ticket) {
+__device__ __forceinline__ bool last_block_arrives(unsigned int* ticket, unsigned int expected) {
   // classic "last block folds" hand-shake: make this workgroup's global writes visible device wide, take a ticket,
   // and if it is the last one make every other workgroup's writes visible to this one
   __shared__ int s_last;
-  __threadfence();          // release: this thread's global writes, device scope (L2 write-back across XCDs)
-  __syncthreads();
+  __syncthreads();          // every store of the workgroup has left the CU (write-through L1) ...
   if (threadIdx.x == 0) {
+    __threadfence();        // ... release at device scope: L2 write-back, visible to the other XCDs
     const unsigned int t = atomicAdd(ticket, 1u);
-    s_last = (t == gridDim.x - 1) ? 1 : 0;
+    s_last = (t == expected - 1) ? 1 : 0;
     if (s_last) *ticket = 0u;   // ready for the next launch (stream ordered)
   }
   __syncthreads();
@@ -77,12 +81,59 @@ __device__ __forceinline__ bool last_block_arrives(unsigned int* ticket) {
   return last;
 }
 
+// Block-wide fold of partial[nrows][ncols] over the rows.  Thread (c, g): column c, row group g of G = 256 / ncols;
+// a thread walks rows g, g+G, ... with four independent accumulators (the loads of a step do not depend on each other:
+// several are in flight), the G group results are combined through LDS in ascending g.  The order of the combination
+// depends only on (nrows, ncols) => deterministic.  finish(c, value) is called by one thread per column.
+template <typename T, typename Op, typename Fin>
+__device__ __forceinline__ void block_fold(const T* __restrict__ partial, int nrows, int ncols, T init, Op op, T* lds,
+                                           Fin finish) {
+  const int Wc = ncols < kThreads ? ncols : kThreads;
+  const int G = kThreads / Wc;
+  const int c0 = threadIdx.x % Wc, g = threadIdx.x / Wc;
+  for (int cb = 0; cb < ncols; cb += Wc) {
+    const int c = cb + c0;
+    T acc = init;
+    if (g < G && c < ncols) {
+      T a0 = init, a1 = init, a2 = init, a3 = init;
+      int b = g;
+      for (; b + 3 * G < nrows; b += 4 * G) {
+        const T x0 = __builtin_nontemporal_load(partial + (int64_t)b * ncols + c);
+        const T x1 = __builtin_nontemporal_load(partial + (int64_t)(b + G) * ncols + c);
+        const T x2 = __builtin_nontemporal_load(partial + (int64_t)(b + 2 * G) * ncols + c);
+        const T x3 = __builtin_nontemporal_load(partial + (int64_t)(b + 3 * G) * ncols + c);
+        a0 = op(a0, x0), a1 = op(a1, x1), a2 = op(a2, x2), a3 = op(a3, x3);
+      }
+      for (; b < nrows; b += G) a0 = op(a0, __builtin_nontemporal_load(partial + (int64_t)b * ncols + c));
+      acc = op(op(a0, a1), op(a2, a3));
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && c < ncols) {
+      for (int gg = 1; gg < G; ++gg) acc = op(acc, lds[gg * Wc + c0]);
+      finish(c, acc);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable tab, const PreArgs a) {
+  __shared__ double fold_lds[kThreads];
   extern __shared__ float tile[];          // [kRows*K] constraint tile + [K] running column maxima
   float* cmax = tile + kRows * a.K;
+  // the id lists of the terms, staged in LDS: the lane-varying lookup ids[j] is then an LDS read in front of the
+  // state load instead of a second global-memory round trip through the kernel-argument segment
+  __shared__ int s_ids[kMaxTerms][CATPPO_TERM_MAX_IDS];
   const int K = a.K, A = a.A, D = a.D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < K; c += kThreads) cmax[c] = -__builtin_inff();
+  for (int o = threadIdx.x; o < tab.n * CATPPO_TERM_MAX_IDS; o += kThreads)
+    s_ids[o / CATPPO_TERM_MAX_IDS][o % CATPPO_TERM_MAX_IDS] = tab.d[o / CATPPO_TERM_MAX_IDS].ids[o % CATPPO_TERM_MAX_IDS];
+  __syncthreads();
+  // observation moments: thread (c, g) = column c, row group g of the 16-row tile (G = 256 / D groups, one when D > 128)
+  const int Dc = D < kThreads ? (D > 0 ? D : 1) : kThreads;
+  const int OG = kThreads / Dc;
+  const int oc = threadIdx.x % Dc, og = threadIdx.x / Dc;
   double os1[kMaxObsPerThread], os2[kMaxObsPerThread];
 #pragma unroll
   for (int q = 0; q < kMaxObsPerThread; ++q) os1[q] = 0.0, os2[q] = 0.0;
@@ -99,7 +150,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
       const int col0 = tab.off[t];
       for (int w = lane; w < rows * W; w += 64) {
         const int e = w / W, j = w - e * W;
-        tile[e * K + col0 + j] = eval_term(d, r0 + e, j, a.forces, a.fstride, a.H, a.B, a.command, a.cld);
+        tile[e * K + col0 + j] = eval_term(d, s_ids[t], r0 + e, j, a.forces, a.fstride, a.H, a.B, a.command, a.cld);
       }
     }
     // ---- counters, terminations, raw reward (cat_env.py:92-97)
@@ -115,16 +166,25 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
       a.reward[i] = a.reward_src[i * a.rw_stride];
     }
     // ---- observation moments of the tile (fp64, fixed order)
-    if (a.obs_raw != nullptr) {
+    if (a.obs_raw != nullptr && og < OG) {
 #pragma unroll
       for (int q = 0; q < kMaxObsPerThread; ++q) {
-        const int c = threadIdx.x + q * kThreads;
+        const int c = oc + q * kThreads;
         if (c < D) {
+          float v[kRows];                         // all loads of the tile first (independent), then the fp64 adds
+#pragma unroll
+          for (int k = 0; k < kRows; ++k) {
+            const int r = og + k * OG;
+            v[k] = r < rows ? a.obs_raw[(r0 + r) * a.obs_ld + c] : 0.0f;
+          }
           double s1 = os1[q], s2 = os2[q];
-          for (int r = 0; r < rows; ++r) {
-            const double v = (double)a.obs_raw[(r0 + r) * a.obs_ld + c];
-            s1 += v;
-            s2 += v * v;
+#pragma unroll
+          for (int k = 0; k < kRows; ++k) {
+            if (og + k * OG < kRows) {
+              const double x = (double)v[k];
+              s1 += x;
+              s2 += x * x;
+            }
           }
           os1[q] = s1, os2[q] = s2;
         }
@@ -148,34 +208,43 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   }
   for (int c = threadIdx.x; c < K; c += kThreads) a.colmax_partial[(int64_t)blockIdx.x * K + c] = cmax[c];
   if (a.obs_raw != nullptr) {
+    // combine the row groups of the block in ascending g (fixed order), one partial row per block
 #pragma unroll
     for (int q = 0; q < kMaxObsPerThread; ++q) {
-      const int c = threadIdx.x + q * kThreads;
-      if (c < D) {
-        a.osum_partial[(int64_t)blockIdx.x * 2 * D + c] = os1[q];
-        a.osum_partial[(int64_t)blockIdx.x * 2 * D + D + c] = os2[q];
+      const int c = oc + q * kThreads;
+      for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        fold_lds[threadIdx.x] = pass == 0 ? os1[q] : os2[q];
+        __syncthreads();
+        if (og == 0 && c < D && (q == 0 || D > kThreads)) {
+          double t = fold_lds[oc];
+          for (int gg = 1; gg < OG; ++gg) t += fold_lds[gg * Dc + oc];
+          a.osum_partial[(int64_t)blockIdx.x * 2 * D + pass * D + c] = t;
+        }
       }
     }
   }
-  if (!last_block_arrives(a.ticket)) return;
-  // ---- last workgroup: fold every partial in fixed order (max is order independent; the fp64 sums are folded
-  //      block 0, 1, 2, ... so the result does not depend on which workgroup happens to be last)
+  // ---- fold tree, two levels, no extra launch: the last workgroup of every group of 32 folds the group's partial rows,
+  //      the last of those folds the group rows into the exchange buffer.  Every fold is at most 32 rows deep, and the
+  //      order of every sum depends only on the grid size - not on which workgroup happens to arrive last.
   const int nblk = gridDim.x;
-  for (int c = threadIdx.x; c < K; c += kThreads) {
-    float m = -__builtin_inff();
-#pragma unroll 8
-    for (int b = 0; b < nblk; ++b) m = nanmax(m, __builtin_nontemporal_load(a.colmax_partial + (int64_t)b * K + c));
-    m = (m < 1e-6f) ? 1e-6f : m;      // clamp(min=1e-6); NaN stays NaN like torch
-    a.x_colmax[c] = m;
-  }
-  if (a.obs_raw != nullptr) {
-    for (int c = threadIdx.x; c < 2 * D; c += kThreads) {
-      double s = 0.0;
-#pragma unroll 8
-      for (int b = 0; b < nblk; ++b) s += __builtin_nontemporal_load(a.osum_partial + (int64_t)b * 2 * D + c);
-      a.x_sums[c] = s;
-    }
-  }
+  const int grp = blockIdx.x / kFoldGroup, n_grp = (nblk + kFoldGroup - 1) / kFoldGroup;
+  const int g0 = grp * kFoldGroup, g_rows = (nblk - g0) < kFoldGroup ? (nblk - g0) : kFoldGroup;
+  if (!last_block_arrives(a.ticket + 1 + grp, (unsigned)g_rows)) return;
+  block_fold<float>(a.colmax_partial + (int64_t)g0 * K, g_rows, K, -__builtin_inff(),
+                    [](float x, float y) { return nanmax(x, y); }, reinterpret_cast<float*>(fold_lds),
+                    [&](int c, float m) { a.colmax_group[(int64_t)grp * K + c] = m; });
+  if (a.obs_raw != nullptr)
+    block_fold<double>(a.osum_partial + (int64_t)g0 * 2 * D, g_rows, 2 * D, 0.0, [](double x, double y) { return x + y; },
+                       fold_lds, [&](int c, double v) { a.osum_group[(int64_t)grp * 2 * D + c] = v; });
+  if (!last_block_arrives(a.ticket, (unsigned)n_grp)) return;
+  block_fold<float>(a.colmax_group, n_grp, K, -__builtin_inff(), [](float x, float y) { return nanmax(x, y); },
+                    reinterpret_cast<float*>(fold_lds), [&](int c, float m) {
+                      a.x_colmax[c] = (m < 1e-6f) ? 1e-6f : m;      // clamp(min=1e-6); NaN stays NaN like torch
+                    });
+  if (a.obs_raw != nullptr)
+    block_fold<double>(a.osum_group, n_grp, 2 * D, 0.0, [](double x, double y) { return x + y; }, fold_lds,
+                       [&](int c, double v) { a.x_sums[c] = v; });
 }
 
 struct TermMetaS {
@@ -346,11 +415,6 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     a.reset_part[((int64_t)blockIdx.x * nt + t) * 2] = sa;
     a.reset_part[((int64_t)blockIdx.x * nt + t) * 2 + 1] = sb;
   }
-  if (threadIdx.x == kThreads - 1) {
-    double n = 0.0;
-    for (int e = 0; e < rows; ++e) n += a.reset[r0 + e] ? 1.0 : 0.0;
-    a.reset_cnt[blockIdx.x] = n;
-  }
   // ---- per env: probability, reward, dones (cat_env.py:102-107,118-121), rollout rows, reset bookkeeping
   if (threadIdx.x < rows) {
     const int e = threadIdx.x;
@@ -363,6 +427,10 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     r = (r < 0.0f) ? 0.0f : r;
     a.reward[i] = r;
     const bool rs = a.reset[i] != 0;
+    {   // envs of this tile that reset: rows <= 32 live in the first half of wave 0
+      const unsigned long long mask = __ballot(rs);
+      if (threadIdx.x == 0) a.reset_cnt[blockIdx.x] = (double)__popcll(mask);
+    }
     const float dn = rs ? 1.0f : p;
     if (a.dones) a.dones[i] = dn;
     if (a.rewards_t != nullptr) {
@@ -385,29 +453,25 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
       a.obs_out[(r0 + r) * a.obs_out_ld + c] = v / s_den[c];
     }
   }
-  if (!last_block_arrives(a.ticket)) return;
+  if (!last_block_arrives(a.ticket, gridDim.x)) return;
   // ---- last workgroup: publish the new state, fold the reset statistics
   for (int c = threadIdx.x; c < K; c += kThreads) a.rm[c] = col_rm[c];
   if (a.obs_raw != nullptr) {
     for (int c = threadIdx.x; c < D; c += kThreads) a.obs_mean[c] = s_mean[c], a.obs_var[c] = s_var[c];
     if (threadIdx.x == 0) a.obs_count[0] = s_tot;
   }
-  if (a.log_out != nullptr && threadIdx.x < nt) {
-    const int t = threadIdx.x;
+  if (a.log_out != nullptr) {
     const int nblk = gridDim.x;
-    double sa = 0.0, sb = 0.0, n = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-      sa += __builtin_nontemporal_load(a.reset_part + ((int64_t)b * nt + t) * 2);
-      sb += __builtin_nontemporal_load(a.reset_part + ((int64_t)b * nt + t) * 2 + 1);
-      n += __builtin_nontemporal_load(a.reset_cnt + b);
-    }
-    if (n > 0.0) {
-      a.log_out[2 * t] = (float)(sa / n) * 100.0f;
-      a.log_out[2 * t + 1] = (float)(sb / n);
-    } else if (a.log_prev != nullptr) {
-      a.log_out[2 * t] = a.log_prev[2 * t];
-      a.log_out[2 * t + 1] = a.log_prev[2 * t + 1];
-    }
+    __shared__ double s_n;
+    block_fold<double>(a.reset_cnt, nblk, 1, 0.0, [](double x, double y) { return x + y; }, red,
+                       [&](int, double v) { s_n = v; });
+    __syncthreads();
+    const double n = s_n;
+    block_fold<double>(a.reset_part, nblk, 2 * nt, 0.0, [](double x, double y) { return x + y; }, red,
+                       [&](int c, double v) {     // column c = 2*t (violation) | 2*t+1 (probability)
+                         if (n > 0.0) a.log_out[c] = (c & 1) ? (float)(v / n) : (float)(v / n) * 100.0f;
+                         else if (a.log_prev != nullptr) a.log_out[c] = a.log_prev[c];
+                       });
   }
 }
 
@@ -454,13 +518,23 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
   }
   const size_t lds = sizeof(float) * ((size_t)kRows * a->K + a->K);
   CATPPO_CHECK_ARG(ctx, lds <= 150 * 1024);
+  // few, fatter workgroups: the partial rows (= grid size) are folded by ONE workgroup at the end of the launch, so
+  // 4096 envs run as 64 workgroups x 4 tiles (64-row fold) rather than 256 x 1
+  // one 16-env tile per workgroup (the term evaluation of a tile is a chain of dependent loads: tiles in sequence
+  // would add their latencies), up to 1024 workgroups; their partial rows are folded by a two-level tree
   int64_t nblk = cdiv64(a->N, kRows);
-  if (nblk > kMaxBlocks) nblk = kMaxBlocks;
+  if (nblk > kMaxPreBlocks) nblk = kMaxPreBlocks;
+  const int64_t n_grp = cdiv64(nblk, kFoldGroup);
+  const int Dq = a->D > 0 ? a->D : 1;
   WsCarver ws(ctx);
   float* cpart = ws.take<float>((uint64_t)nblk * a->K);
-  double* opart = ws.take<double>((uint64_t)nblk * 2 * (a->D > 0 ? a->D : 1));
+  double* opart = ws.take<double>((uint64_t)nblk * 2 * Dq);
+  float* cgrp = ws.take<float>((uint64_t)n_grp * a->K);
+  double* ogrp = ws.take<double>((uint64_t)n_grp * 2 * Dq);
   CATPPO_NEED_WS(ctx, cpart);
   CATPPO_NEED_WS(ctx, opart);
+  CATPPO_NEED_WS(ctx, cgrp);
+  CATPPO_NEED_WS(ctx, ogrp);
   PreArgs p{};
   p.N = a->N, p.A = a->A, p.D = a->D, p.K = a->K;
   p.action_in = a->action_in, p.action = a->action, p.prev_action = a->prev_action;
@@ -473,9 +547,10 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
   p.cstr = a->cstr;
   p.obs_raw = a->obs_raw, p.obs_ld = a->obs_ld;
   p.colmax_partial = cpart, p.osum_partial = opart;
+  p.colmax_group = cgrp, p.osum_group = ogrp;
   p.x_colmax = static_cast<float*>(a->xchg);
   p.x_sums = reinterpret_cast<double*>(static_cast<char*>(a->xchg) + xchg_sum_offset(a->K));
-  p.ticket = ctx->tickets + 0;
+  p.ticket = ctx->tickets + catppo_ctx::kTicketPre;      // [0] launch, [1 .. 32] groups
   hipLaunchKernelGGL(rollout_pre_kernel, dim3((unsigned)nblk), dim3(kThreads), lds, static_cast<hipStream_t>(stream), tab,
                      p);
   CATPPO_CHECK_LAUNCH(ctx);
@@ -526,7 +601,7 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   p.x_colmax = static_cast<const float*>(a->xchg);
   p.x_sums = reinterpret_cast<const double*>(static_cast<const char*>(a->xchg) + xchg_sum_offset(K));
   p.reset_part = rpart, p.reset_cnt = rcnt;
-  p.ticket = ctx->tickets + 1;
+  p.ticket = ctx->tickets + catppo_ctx::kTicketPost;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_post_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -33,29 +33,31 @@ __device__ __forceinline__ float force_peak(const float* forces, int64_t fstride
   return m;
 }
 
-__device__ __forceinline__ float eval_term(const catppo_term_desc& d, int64_t env, int j, const float* forces,
-                                           int64_t fstride, int H, int B, const float* command, int cld) {
+// `ids`: the term's id list (d.ids, or a copy of it in LDS)
+__device__ __forceinline__ float eval_term(const catppo_term_desc& d, const int32_t* ids, int64_t env, int j,
+                                           const float* forces, int64_t fstride, int H, int B, const float* command,
+                                           int cld) {
   float out = 0.0f;
   switch (d.kind) {
     case CATPPO_TERM_ABS_LIMIT: {
-      out = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
+      out = fabsf(d.x[env * d.x_ld + ids[j]]) - d.limit;
     } break;
     case CATPPO_TERM_ABS_DIFF_LIMIT: {
-      const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
+      const float df = d.x[env * d.x_ld + ids[j]] - d.y[env * d.y_ld + ids[j]];
       out = fabsf(df) - d.limit;
     } break;
     case CATPPO_TERM_ABS_DIFF_LIMIT_GATE_CMDY: {
-      const float df = d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]];
+      const float df = d.x[env * d.x_ld + ids[j]] - d.y[env * d.y_ld + ids[j]];
       const float c = fabsf(df) - d.limit;
       const float gate = fabsf(command[env * cld + 1]) < d.aux ? 1.0f : 0.0f;
       out = c * gate;
     } break;
     case CATPPO_TERM_GREATER: {
-      out = d.x[env * d.x_ld + d.ids[0]] > d.limit ? 1.0f : 0.0f;
+      out = d.x[env * d.x_ld + ids[0]] > d.limit ? 1.0f : 0.0f;
     } break;
     case CATPPO_TERM_CONTACT_ANY: {
       bool any = false;
-      for (int b = 0; b < d.n_ids; ++b) any = any || (force_peak(forces, fstride, env, H, B, d.ids[b]) > d.limit);
+      for (int b = 0; b < d.n_ids; ++b) any = any || (force_peak(forces, fstride, env, H, B, ids[b]) > d.limit);
       out = any ? 1.0f : 0.0f;
     } break;
     case CATPPO_TERM_NORM2_LIMIT: {
@@ -66,30 +68,30 @@ __device__ __forceinline__ float eval_term(const catppo_term_desc& d, int64_t en
     } break;
     case CATPPO_TERM_AIR_TIME: {
       const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
-      float c = d.limit - d.x[env * d.x_ld + d.ids[j]];
-      c = c * d.y[env * d.y_ld + d.ids[j]];
+      float c = d.limit - d.x[env * d.x_ld + ids[j]];
+      c = c * d.y[env * d.y_ld + ids[j]];
       out = c * gate;
     } break;
     case CATPPO_TERM_N_FOOT_CONTACT: {
       int n = 0;
-      for (int b = 0; b < d.n_ids; ++b) n += force_peak(forces, fstride, env, H, B, d.ids[b]) > 1.0f ? 1 : 0;
+      for (int b = 0; b < d.n_ids; ++b) n += force_peak(forces, fstride, env, H, B, ids[b]) > 1.0f ? 1 : 0;
       int diff = n - (int)d.limit;
       diff = diff < 0 ? -diff : diff;
       const float gate = norm3(command + env * cld) > d.aux ? 1.0f : 0.0f;
       out = (float)diff * gate;
     } break;
     case CATPPO_TERM_ACTION_RATE: {
-      const float df = fabsf(d.x[env * d.x_ld + d.ids[j]] - d.y[env * d.y_ld + d.ids[j]]);
+      const float df = fabsf(d.x[env * d.x_ld + ids[j]] - d.y[env * d.y_ld + ids[j]]);
       out = df / d.aux - d.limit;
     } break;
     case CATPPO_TERM_FORCE_LIMIT: {
-      out = force_peak(forces, fstride, env, H, B, d.ids[j]) - d.limit;
+      out = force_peak(forces, fstride, env, H, B, ids[j]) - d.limit;
     } break;
     case CATPPO_TERM_LIMIT_MINUS: {
-      out = d.limit - d.x[env * d.x_ld + d.ids[0]];
+      out = d.limit - d.x[env * d.x_ld + ids[0]];
     } break;
     case CATPPO_TERM_ABS_LIMIT_GATE_CMDNORM_LT: {
-      const float c = fabsf(d.x[env * d.x_ld + d.ids[j]]) - d.limit;
+      const float c = fabsf(d.x[env * d.x_ld + ids[j]]) - d.limit;
       const float gate = norm3(command + env * cld) < d.aux ? 1.0f : 0.0f;
       out = c * gate;
     } break;

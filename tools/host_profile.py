@@ -18,7 +18,7 @@ torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(5):
-    trainer.rollout()
+    trainer.run_iteration(log=False)
     torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
