@@ -405,7 +405,10 @@ class PPOTrainer:
         if g is None:
             g = min(self.mb, self.batch) <= 4096
         dist_on_torch = parallel.active() and not parallel.native_comm_active()
-        self.graph_update = bool(g) and self.rng == "device" and not dist_on_torch
+        # RCCL collectives inside a captured graph are exercised on a world of one here (a one-GPU box); with real
+        # peers they stay opt-in (CATPPO_GRAPH_COMM=1) until measured on a multi-GPU node
+        dist_in_graph_ok = self.world == 1 or os.environ.get("CATPPO_GRAPH_COMM") == "1"
+        self.graph_update = bool(g) and self.rng == "device" and not dist_on_torch and dist_in_graph_ok
         self._graph_id = None
         self.graph_nodes = 0
         self.stream = torch.cuda.Stream(device=dev) if self.graph_update else None

@@ -7,4 +7,4 @@ time-outs, ``discount_values`` on float dones (rl_games/cat_common.py:35-112, ca
 provided as device functions with the same argument meaning.
 """
 from .cat_common import bootstrap_time_outs, discount_values  # noqa: F401
-from .cat_experience import CaTExperienceBuffer  # noqa: F401
+from .cat_experience import CaTExperienceBuffer, swap_and_flatten01  # noqa: F401
