@@ -112,6 +112,31 @@ def _worker(rank, world, port, out_dir):
     assert float((g - g_ref).abs().max()) < 1e-6 * max(1.0, float(g_ref.abs().max())), float((g - g_ref).abs().max())
     res["grad"] = True
 
+    # ---- 3b. ragged shards (51 / 50 rows): the TRUE global row count travels with the sums (round 1 assumed equal
+    #          shards); exchange buffer of the fused rollout step = {colmax MAX | moment sums SUM}
+    xr = (rs.standard_normal((101, 7)) * 2 - 0.5).astype(np.float32)
+    slr = parallel.shard_slice(101, rank, world)
+    loc = torch.from_numpy(xr[slr]).double()
+    sums = torch.cat([loc.sum(0), (loc * loc).sum(0)])
+    cnt = torch.tensor([float(loc.shape[0])], dtype=torch.float64)
+    colmax = torch.from_numpy(np.maximum(xr[slr].max(0), np.float32(1e-6)))
+    parallel.allreduce_sum_(sums)
+    parallel.allreduce_sum_(cnt)
+    parallel.allreduce_max_(colmax)
+    assert float(cnt) == 101.0 and np.array_equal(colmax.numpy(), np.maximum(xr.max(0), np.float32(1e-6)))
+    allx = torch.from_numpy(xr).double()
+    assert torch.allclose(sums[:7] / cnt, allx.mean(0), rtol=1e-12) and \
+        torch.allclose(sums[7:] / cnt - (sums[:7] / cnt) ** 2, allx.var(0, correction=0), rtol=1e-9)
+    # ---- 3c. KL of the adaptive schedule: each rank's diag carries sum_i kl_i / (M_local * world); the SUM over ranks is
+    #          the global mean (skrl: all_reduce(kl, SUM) / world_size, skrl/ppo.py:562-564)
+    kl_rows = rs.uniform(0, 0.05, 256).astype(np.float64)
+    slk = parallel.shard_slice(256, rank, world)
+    kl_local = torch.tensor([kl_rows[slk].sum() / (len(kl_rows[slk]) * world)], dtype=torch.float64)
+    parallel.allreduce_sum_(kl_local)
+    assert abs(float(kl_local) - kl_rows.mean()) < 1e-12
+    # no HIP device here: the native RCCL communicator is not used, torch.distributed carries the exchange
+    assert not parallel.native_comm_active()
+
     # ---- 4. broadcast of the flat parameters from rank 0
     flat = torch.full((10,), float(rank))
     parallel.broadcast_(flat, src=0)
