@@ -70,11 +70,11 @@ class CaT:
         sc = self._scratch.get(name)
         if sc is None or sc[0].shape != (n, width):
             sc = (torch.empty(n, width, device=nat.device), torch.empty(n, device=nat.device),
-                  torch.zeros(1, n, device=nat.device), torch.zeros(1, n, device=nat.device))
+                  torch.zeros(1, n, device=nat.device), torch.zeros(1, n, device=nat.device),
+                  (C.c_int32 * 2)(0, width), (C.c_float * 1)())          # host argument arrays, made once per term
             self._scratch[name] = sc
-        probs, prob_max, viol, eprob = sc
-        off = (C.c_int32 * 2)(0, width)
-        dp = (C.c_float * 1)(native.f32(max_p - self.min_p))
+        probs, prob_max, viol, eprob, off, dp = sc
+        dp[0] = max_p - self.min_p                                        # double -> fp32 (RNE) in the assignment
         nat.cat_step(c, off, dp, self.min_p, self.tau, first, self.running_maxes[name].view(-1), prob_max, viol,
                      eprob, probs=probs)
         self.raw_constraints[name] = c

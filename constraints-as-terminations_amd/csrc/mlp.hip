@@ -134,9 +134,16 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
 
 // ------------------------------------------------------------------------------- GEMM launch
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-void launch_gemm(const Params& p, hipStream_t s, int prec) {
+void launch_gemm(const Params& p, hipStream_t s, int prec, size_t lds_pad = 0) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);   // 1-D tile index, see kernel
-  constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
+  const size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>() + lds_pad;
+  if (lds_pad && prec == 0) {   // residency experiment (CATPPO_FWD_LDS_PAD): fp32 forward GEMMs only
+    auto kern = gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    kern<<<grid, dim3(256), lds, s>>>(p);
+    return;
+  }
   if (prec == 2)
     gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, 2><<<grid, dim3(256), lds, s>>>(p);
   else if (prec == 1)
@@ -155,6 +162,29 @@ void launch_gemm_auto(const Params& p, hipStream_t s, int prec) {
   // weight gradients pick their split count to fill the chip, so only the shape matters there
   const bool use_big = EPI != gemm::EPI_MUL_DELU && p.I >= 128 && p.J >= 128 && kc >= 256 &&
                        (EPI == gemm::EPI_PARTIAL || big >= 384);
+  if constexpr (EPI == gemm::EPI_BIAS_ELU) {
+    // experiment hooks (A/B on the GPU box): CATPPO_FWD_TILE = 64x64 | 64x128 | 128x64, CATPPO_FWD_LDS_PAD = bytes of
+    // unused LDS per workgroup (caps the number of resident workgroups per CU => the grid runs in several rounds)
+    static const int tile_sel = [] {
+      const char* e = getenv("CATPPO_FWD_TILE");
+      if (!e) return 0;
+      if (!strcmp(e, "64x64")) return 1;
+      if (!strcmp(e, "64x128")) return 2;
+      if (!strcmp(e, "128x64")) return 3;
+      return 0;
+    }();
+    static const size_t pad = [] {
+      const char* e = getenv("CATPPO_FWD_LDS_PAD");
+      return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    if (use_big && (tile_sel || pad)) {
+      if (tile_sel == 1) launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, prec, pad);
+      else if (tile_sel == 2) launch_gemm<64, 128, A_KC, B_KC, EPI>(p, s, prec, pad);
+      else if (tile_sel == 3) launch_gemm<128, 64, A_KC, B_KC, EPI>(p, s, prec, pad);
+      else launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, prec, pad);
+      return;
+    }
+  }
   if (use_big)
     launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, prec);
   else
@@ -724,8 +754,6 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
   for (int o = tid; o < NS; o += NT) ps[o] = ls[o];
 }
 
-#include "fused_rows.h"
-
 // ------------------------------------------------------------------------------- segmented partial reduction
 // dst[e] (+)= scale * sum_{p<n_parts} src[p*stride + e]   in fixed order.  One launch handles every segment
 // (all split-K weight/bias partials, the head partials and the diagnostics).
@@ -832,56 +860,6 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
   }
 }
 
-void fill_fused(FusedArgs& f, const catppo_mlp_shape* sh, const catppo_mlp_layout& L, const float* params,
-                const float* x, int64_t M, const MlpWs& w, bool training) {
-  f = FusedArgs{};
-  f.x = x, f.params = params, f.n_hidden = sh->n_hidden, f.A = sh->act_dim, f.Dp = L.obs_pad, f.M = M;
-  f.off_logstd = L.off_logstd;
-  for (int l = 0; l < sh->n_hidden; ++l) f.hidden[l] = sh->hidden[l];
-  for (int net = 0; net < 2; ++net)
-    for (int l = 0; l <= sh->n_hidden; ++l) f.off_w[net][l] = L.off_w[net][l], f.off_b[net][l] = L.off_b[net][l];
-  if (training)
-    for (int net = 0; net < 2; ++net)
-      for (int l = 0; l < sh->n_hidden; ++l) f.H[net][l] = w.H[net][l], f.dZ[net][l] = w.dZ[net][l];
-}
-
-// 0: layer-wise path; otherwise 1 + variant of the fused row-tile kernel (see launch_fused)
-int fused_variant(const catppo_mlp_shape* sh) {
-  static const int forced = [] {
-    // measured on MI355X (profiles/): the fused kernel is correct but 10-20 % SLOWER than the
-    // layer-wise path (one workgroup per CU runs its phases in lock-step, so head / epilogue phases
-    // never overlap MFMA work), hence opt-in: "1".."3" selects a variant, unset / "0" = layer-wise
-    const char* e = getenv("CATPPO_FUSED");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced <= 0 || sh->mfma_bf16) return 0;   // the row-tile kernel has no bf16-operand variant
-  int maxw = 0;
-  for (int l = 0; l < sh->n_hidden; ++l) maxw = sh->hidden[l] > maxw ? sh->hidden[l] : maxw;
-  if (maxw > 512) return 0;
-  if (maxw > 256) return 3;
-  return forced >= 3 ? 3 : forced;
-}
-inline int fused_rows(int variant_plus1) { return variant_plus1 == 1 ? 64 : 32; }
-
-template <int R, int MAXW, int NW, bool TRAIN>
-void launch_fused_cfg(const FusedArgs& f, int nets, hipStream_t s) {
-  constexpr size_t lds = fused_lds_bytes<R, MAXW>();
-  auto kern = fused_rows_kernel<R, MAXW, NW, TRAIN>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  kern<<<dim3((unsigned)cdiv64(f.M, R), nets), dim3(NW * 64), lds, s>>>(f);
-}
-
-// variant: 0 = 64-row tiles / 8 waves (one workgroup per CU), 1 = 32-row tiles / 4 waves (two independent
-// workgroups per CU: their barrier bubbles overlap), 2 = 32-row tiles / 8 waves for widths up to 512
-template <bool TRAIN>
-int launch_fused(catppo_ctx* ctx, const FusedArgs& f, int variant, int nets, hipStream_t s) {
-  if (variant == 0) launch_fused_cfg<64, 256, 8, TRAIN>(f, nets, s);
-  else if (variant == 1) launch_fused_cfg<32, 256, 4, TRAIN>(f, nets, s);
-  else launch_fused_cfg<32, 512, 8, TRAIN>(f, nets, s);
-  CATPPO_CHECK_LAUNCH(ctx);
-  return CATPPO_OK;
-}
-
 template <typename F>
 int dispatch_cpl(int hl, F&& f) {
   switch (hl) {
@@ -931,14 +909,6 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
   CATPPO_CHECK_ARG(ctx, params && x && value && (critic_only || (action && logprob)));
   CATPPO_CHECK_ARG(ctx, value_dtype == CATPPO_F32 || value_dtype == CATPPO_F16);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int fv = fused_variant(shape);
-  if (fv && value_dtype == CATPPO_F32 && rng_state == nullptr) {
-    FusedArgs f;
-    fill_fused(f, shape, L, params, x, N, w, false);
-    if (!critic_only) f.eps = eps, f.given = given_action, f.action = action, f.logprob = logprob;
-    f.value = static_cast<float*>(value);
-    return launch_fused<false>(ctx, f, fv - 1, critic_only ? 1 : 2, s);   // grid.y == 1: critic task only
-  }
   forward_hidden(shape, L, params, x, N, w, 0, critic_only ? 1 : 2, s);
   CATPPO_CHECK_LAUNCH(ctx);
   const int nl = shape->n_hidden, A = critic_only ? 0 : shape->act_dim;
@@ -1112,21 +1082,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const int head_cap = 2 * head_lds > 160 * 1024 ? kHeadMaxBlocks / 2 : kHeadMaxBlocks;
   if (nbh > head_cap) nbh = head_cap;
 
-  const int fv = fused_variant(shape);
-  const int rpt = fv ? fused_rows(fv) : 0;
-  if (rpt) {
-    // 2-3 (fused). forward chain, heads + losses, data-gradient chain: ONE launch, activations in LDS
-    nbh = (int)cdiv64(M, rpt);
-    FusedArgs f;
-    fill_fused(f, shape, L, params, w.xmb, M, w, true);
-    f.act = w.act, f.oldlogp = w.scal, f.adv = w.scal + M, f.ret_n = w.scal + 2 * M, f.val_n = w.scal + 3 * M;
-    f.adv_part = w.adv_part, f.n_adv_part = nbg;
-    f.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
-    f.vrms_mean = vrms_mean, f.vrms_var = vrms_var;
-    f.part_w = w.head_w, f.part_s = w.head_s;
-    f.hp = *hp;
-    if (int rc = launch_fused<true>(ctx, f, fv - 1, 2, s)) return rc;
-  } else {
+  {
     // 2. hidden layers forward, both nets per launch
     forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s);
     CATPPO_CHECK_LAUNCH(ctx);
@@ -1227,7 +1183,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       pw.op[net].dbias = w.bpart[l] + (int64_t)net * splits * out;   // [net][split][out]
     }
     static const bool no_pair = getenv("CATPPO_NO_PAIR") != nullptr;
-    const bool pair = l > 0 && !rpt && !fork && !no_pair;
+    const bool pair = l > 0 && !fork && !no_pair;
     if (!pair) {
       launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
       CATPPO_CHECK_LAUNCH(ctx);
@@ -1247,8 +1203,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
       add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, nbh, 1, hp->inv_global_batch);
     }
-    if (l > 0 && !rpt) {
-      // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})   (the fused kernel already produced it)
+    if (l > 0) {
+      // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
       Params px{};
       px.nets = 2;
       px.splits = 1;

@@ -129,22 +129,6 @@ def test_env_sharded_code_path_on_one_gpu():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("variant", ["1", "2"])
-def test_fused_row_tile_kernel_variants(variant):
-    """CATPPO_FUSED=1|2 (opt-in, measured slower than the layer-wise path): forward chain + heads + losses +
-    data-gradient chain in one launch must pass the same minibatch / policy parity tests."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, CATPPO_FUSED=variant)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-m", "gpu",
-                        "-q", "-p", "no:cacheprovider", "-k", "minibatch or policy"], env=env, cwd=root,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout and "error" not in r.stdout.lower(), r.stdout[-500:]
-
-
 def test_train_and_play_entry_points(tmp_path):
     """scripts/clean_rl/train.py with the reference's flags, checkpoint written with the reference's naming,
     then scripts/clean_rl/play.py loads it and rolls the policy out."""
