@@ -58,6 +58,16 @@ def main():
         out.append(dict(kernel="gae[fp16 planes]", T=T, N=N, us=us, GBps=byt / us / 1e3, frac_8TBps=byt / us / 1e3 / 8000))
         del x, adv, ret
 
+    # ---- GAE scan mode (wavefront-shuffle scan over time) at the sizes where the serial kernel is latency bound
+    for T, N in [(24, 4096), (48, 4096), (24, 2048), (24, 32768)]:
+        x = [torch.rand(T, N, device=dev) for _ in range(4)]
+        nv, nd, ntd = (torch.rand(N, device=dev) for _ in range(3))
+        adv, ret = torch.empty(T, N, device=dev), torch.empty(T, N, device=dev)
+        for mode, name in ((native.GAE_SERIAL, "gae serial"), (native.GAE_SCAN, "gae scan")):
+            us = timeit(lambda: nat.gae_mode(mode, x[0], x[1], x[2], x[3], nv, nd, ntd, 0.99, 0.95, adv, ret), a.reps)
+            out.append(dict(kernel=name + " (launch loop: launch-rate bound below ~7 us)", T=T, N=N, us=us,
+                            GBps=(24 * T * N + 12 * N) / us / 1e3))
+
     # ---- CaT step
     for N, widths in [(4096, [12, 12, 1, 4, 12, 1]), (4096, [12, 12, 12, 12, 1, 4, 2, 1, 4, 1, 4, 12, 1]),
                       (32768, [12, 12, 12, 12, 1, 4, 2, 1, 4, 1, 4, 12, 1])]:
@@ -88,10 +98,11 @@ def main():
         out.append(dict(kernel="rms update+normalize(4 launches)", N=N, D=D, us=us, GBps=N * D * 12 / us / 1e3))
 
     # ---- MLP
-    for D, hidden, bf16 in [(45, (512, 256, 128), False), (48, (256, 256, 256), False), (48, (256, 256, 256), True)]:
+    for D, hidden, bf16 in [(45, (512, 256, 128), 0), (48, (256, 256, 256), 0), (48, (256, 256, 256), 2),
+                            (48, (256, 256, 256), 1)]:
         A = 12
         shape = native.shape_of(D, A, hidden, mfma_bf16=bf16)
-        tag = "[bf16 operands]" if bf16 else ""
+        tag = {0: "", 1: "[bf16 operands]", 2: "[bf16x3 split operands]"}[bf16]
         lay = native.layout_of(shape)
         dims = [lay.obs_pad, *hidden]
         macs_true = sum(i * o for i, o in zip([D, *hidden[:-1]], hidden)) * 2 + hidden[-1] * (A + 1)
@@ -121,6 +132,39 @@ def main():
         m1, m2 = torch.zeros(lay.n_flat, device=dev), torch.zeros(lay.n_flat, device=dev)
         us = timeit(lambda: nat.clip_adam(params, grad, m1, m2, lay.n_flat, 1.0, 3e-4, 0.9, 0.999, 1e-5, 3), a.reps)
         out.append(dict(kernel="clip_adam(2 launches)", n=int(lay.n_flat), us=us, GBps=lay.n_flat * 28 / us / 1e3))
+        if bf16 == 0:
+            st = nat.iter_state_new(1, 3e-4)
+            nat.iter_begin(st, 3e-4, 10, native.LR_FIXED)
+            us = timeit(lambda: nat.clip_adam_dev(params, grad, m1, m2, lay.n_flat, 1.0, 0.9, 0.999, 1e-5, st), a.reps)
+            out.append(dict(kernel="clip_adam_dev(2 launches, lr/step on the device)", n=int(lay.n_flat), us=us))
+            x = torch.randn(4096, lay.obs_pad, device=dev)
+            act, lp, val = torch.empty(4096, A, device=dev), torch.empty(4096, device=dev), torch.empty(4096, device=dev)
+            us = timeit(lambda: nat.policy_act_rng(shape, params, x, 4096, st, 3, act, lp, val), a.reps)
+            out.append(dict(kernel="policy_act_rng (Philox noise in the head kernel)", arch=list(hidden), N=4096, us=us))
+            n_mb, parts = B // M, (M + nat.GATHER_ROWS - 1) // nat.GATHER_ROWS
+            xg, ag = torch.empty(B, lay.obs_pad, device=dev), torch.empty(B, A, device=dev)
+            sg, ap = torch.empty(4 * B, device=dev), torch.empty(n_mb * parts * 2, dtype=torch.float64, device=dev)
+            perm = torch.randperm(B, device=dev)
+            us = timeit(lambda: nat.ppo_gather_ex(shape, obs, acts, logp, adv, ret, val, B, M, xg, ag, sg, ap, st=st), a.reps)
+            us2 = timeit(lambda: nat.ppo_gather_ex(shape, obs, acts, logp, adv, ret, val, B, M, xg, ag, sg, ap, inds=perm),
+                         a.reps)
+            us3 = timeit(lambda: torch.randperm(B, device=dev), a.reps)
+            out.append(dict(kernel="epoch gather, keyed permutation inside", B=B, us=us, with_index_array_us=us2,
+                            torch_randperm_alone_us=us3))
+
+    # ---- one env step of the rollout (policy forward + fused env step), cfg2
+    sys.path.insert(0, ROOT)
+    import bench
+    for wl in ("cfg2", "reference"):
+        env, trainer, _ = bench.build(wl, 42, 0, overrides={"graph_update": False})
+        for _ in range(2):
+            trainer.run_iteration(log=False)
+        trainer.time_phases = True
+        for _ in range(5):
+            trainer.run_iteration(log=False)
+        ph = trainer.phase_summary()
+        out.append(dict(kernel=f"rollout step ({wl}): policy forward 4 launches + state copy + rollout_pre + rollout_post",
+                        us=1e3 * ph["rollout_ms"] / trainer.T, fused=trainer.sink is not None))
 
     for o in out:
         print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in o.items()}))
