@@ -214,6 +214,9 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="PPO cfg override, e.g. --set graph_update=True --set rng=torch --set fused_rollout=False")
     ap.add_argument("--profile-tag", default="r2", help="prefix of the PMC summaries under profiles/")
+    ap.add_argument("--shard-of", type=int, default=0, metavar="W",
+                    help="single process, no collectives: run ONE rank's share of a strong-scaling workload as if the "
+                         "world had W ranks (compute side of the scaling curve on a one-GPU box)")
     ap.add_argument("--seed", type=int, default=42)
     a = ap.parse_args()
 
@@ -244,7 +247,8 @@ def main():
         except (ValueError, SyntaxError):
             overrides[k] = v
     w = WORKLOADS[a.workload]
-    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision, world, rank, overrides)
+    shard_world = a.shard_of if (a.shard_of > 0 and world == 1) else world
+    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision, shard_world, rank, overrides)
     nat = trainer.nat
     from cat_envs import parallel
 
@@ -341,6 +345,7 @@ def main():
                        "collectives": "libcatppo C ABI (librccl)" if parallel.native_comm_active() else
                                       ("torch.distributed" if world > 1 else "none"),
                        "timed_region": "K x run_iteration(log=True): includes the per-iteration diagnostics read-back",
+                       "simulated_shard_of_world": a.shard_of if a.shard_of > 0 else None,
                        "rng": trainer.rng, "fused_rollout": trainer.sink is not None,
                        "graph_update": trainer.graph_update, "graph_nodes": trainer.graph_nodes,
                        "overrides": overrides},
