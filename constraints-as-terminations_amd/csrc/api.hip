@@ -75,6 +75,12 @@ extern "C" int catppo_reserve(catppo_ctx* ctx, uint64_t bytes) {
   (void)hipSetDevice(ctx->device);
   // the old block may still be referenced by enqueued kernels: drain before freeing
   (void)hipDeviceSynchronize();
+  // release the old block BEFORE asking for the bigger one: the allocator can then extend / reuse its address range
+  // instead of placing the new block wherever a hole of that size is left (a workspace that grew after other
+  // allocations was measured 1.7x slower for the GEMMs that live in it - fragmented placement)
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  ctx->ws = nullptr;
+  ctx->ws_bytes = 0;
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
@@ -82,7 +88,6 @@ extern "C" int catppo_reserve(catppo_ctx* ctx, uint64_t bytes) {
     return catppo_fail(ctx, CATPPO_E_HIP, "catppo_reserve: hipMalloc(%llu) failed: %s", (unsigned long long)bytes,
                        hipGetErrorString(e));
   }
-  if (ctx->ws) (void)hipFree(ctx->ws);
   // captured graphs hold pointers into the old block: drop them (catppo_graph_launch then fails and the caller
   // captures again)
   for (auto& g : ctx->graphs)

@@ -38,6 +38,7 @@ def main():
     dev = "cuda"
     out = []
 
+    torch.cuda.synchronize(); print("[microbench] next: GAE: config size and HBM-roofline sweep (24 B per env-step)", file=sys.stderr, flush=True)
     # ---- GAE: config size and HBM-roofline sweep (24 B per env-step)
     for T, N in [(24, 4096), (48, 4096), (24, 32768), (24, 1 << 18), (24, 1 << 20), (48, 1 << 22)]:
         x = [torch.rand(T, N, device=dev) for _ in range(4)]
@@ -48,6 +49,7 @@ def main():
         out.append(dict(kernel="gae", T=T, N=N, us=us, GBps=byt / us / 1e3, frac_8TBps=byt / us / 1e3 / 8000))
         del x, adv, ret
 
+    torch.cuda.synchronize(); print("[microbench] next: GAE on fp16 planes (12 B per env-step)", file=sys.stderr, flush=True)
     # ---- GAE on fp16 planes (12 B per env-step)
     for T, N in [(24, 32768), (24, 1 << 20), (48, 1 << 22)]:
         x = [torch.rand(T, N, device=dev).half() for _ in range(4)]
@@ -58,6 +60,7 @@ def main():
         out.append(dict(kernel="gae[fp16 planes]", T=T, N=N, us=us, GBps=byt / us / 1e3, frac_8TBps=byt / us / 1e3 / 8000))
         del x, adv, ret
 
+    torch.cuda.synchronize(); print("[microbench] next: GAE scan mode (wavefront-shuffle scan over time) at the size", file=sys.stderr, flush=True)
     # ---- GAE scan mode (wavefront-shuffle scan over time) at the sizes where the serial kernel is latency bound
     for T, N in [(24, 4096), (48, 4096), (24, 2048), (24, 32768)]:
         x = [torch.rand(T, N, device=dev) for _ in range(4)]
@@ -68,6 +71,7 @@ def main():
             out.append(dict(kernel=name + " (launch loop: launch-rate bound below ~7 us)", T=T, N=N, us=us,
                             GBps=(24 * T * N + 12 * N) / us / 1e3))
 
+    torch.cuda.synchronize(); print("[microbench] next: CaT step", file=sys.stderr, flush=True)
     # ---- CaT step
     for N, widths in [(4096, [12, 12, 1, 4, 12, 1]), (4096, [12, 12, 12, 12, 1, 4, 2, 1, 4, 1, 4, 12, 1]),
                       (32768, [12, 12, 12, 12, 1, 4, 2, 1, 4, 1, 4, 12, 1])]:
@@ -84,6 +88,7 @@ def main():
         byt = N * (4 * K + 4 + 4 + 8 + 16 * nt)
         out.append(dict(kernel="cat_step(3 launches)", N=N, K=K, n_terms=nt, us=us, GBps=byt / us / 1e3))
 
+    torch.cuda.synchronize(); print("[microbench] next: obs normaliser", file=sys.stderr, flush=True)
     # ---- obs normaliser
     for N, D in [(4096, 45), (4096, 235), (98304, 1)]:
         x = torch.randn(N, D, device=dev)
@@ -97,6 +102,7 @@ def main():
         us = timeit(f, a.reps)
         out.append(dict(kernel="rms update+normalize(4 launches)", N=N, D=D, us=us, GBps=N * D * 12 / us / 1e3))
 
+    torch.cuda.synchronize(); print("[microbench] next: MLP", file=sys.stderr, flush=True)
     # ---- MLP
     for D, hidden, bf16 in [(45, (512, 256, 128), 0), (48, (256, 256, 256), 0), (48, (256, 256, 256), 2),
                             (48, (256, 256, 256), 1)]:
@@ -138,8 +144,9 @@ def main():
             us = timeit(lambda: nat.clip_adam_dev(params, grad, m1, m2, lay.n_flat, 1.0, 0.9, 0.999, 1e-5, st), a.reps)
             out.append(dict(kernel="clip_adam_dev(2 launches, lr/step on the device)", n=int(lay.n_flat), us=us))
             x = torch.randn(4096, lay.obs_pad, device=dev)
-            act, lp, val = torch.empty(4096, A, device=dev), torch.empty(4096, device=dev), torch.empty(4096, device=dev)
-            us = timeit(lambda: nat.policy_act_rng(shape, params, x, 4096, st, 3, act, lp, val), a.reps)
+            act_r, lp_r, val_r = (torch.empty(4096, A, device=dev), torch.empty(4096, device=dev),
+                                  torch.empty(4096, device=dev))
+            us = timeit(lambda: nat.policy_act_rng(shape, params, x, 4096, st, 3, act_r, lp_r, val_r), a.reps)
             out.append(dict(kernel="policy_act_rng (Philox noise in the head kernel)", arch=list(hidden), N=4096, us=us))
             n_mb, parts = B // M, (M + nat.GATHER_ROWS - 1) // nat.GATHER_ROWS
             xg, ag = torch.empty(B, lay.obs_pad, device=dev), torch.empty(B, A, device=dev)
@@ -151,20 +158,6 @@ def main():
             us3 = timeit(lambda: torch.randperm(B, device=dev), a.reps)
             out.append(dict(kernel="epoch gather, keyed permutation inside", B=B, us=us, with_index_array_us=us2,
                             torch_randperm_alone_us=us3))
-
-    # ---- one env step of the rollout (policy forward + fused env step), cfg2
-    sys.path.insert(0, ROOT)
-    import bench
-    for wl in ("cfg2", "reference"):
-        env, trainer, _ = bench.build(wl, 42, 0, overrides={"graph_update": False})
-        for _ in range(2):
-            trainer.run_iteration(log=False)
-        trainer.time_phases = True
-        for _ in range(5):
-            trainer.run_iteration(log=False)
-        ph = trainer.phase_summary()
-        out.append(dict(kernel=f"rollout step ({wl}): policy forward 4 launches + state copy + rollout_pre + rollout_post",
-                        us=1e3 * ph["rollout_ms"] / trainer.T, fused=trainer.sink is not None))
 
     for o in out:
         print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in o.items()}))
