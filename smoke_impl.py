@@ -54,6 +54,7 @@ def run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=1, hidden=
     for k, v in (agent_overrides or {}).items():
         setattr(agent_cfg, k, v)
     env = make(task, cfg=env_cfg)
+    torch.manual_seed(seed)                      # the Agent's orthogonal initialisation draws from torch's generator
     trainer = PPOTrainer(env, agent_cfg)
     sd = {k: v.detach().cpu().clone() for k, v in trainer.agent.state_dict().items()}
     cpu_env = env_oracle.from_device_env(env)
