@@ -481,6 +481,73 @@ def test_bf16x3_whole_iteration_vs_fp32_oracle():
     assert rep["logprobs"] < 1e-2 and rep["params"] < 5e-4, rep
 
 
+def test_rl_games_experience_buffer_contract_and_returns():
+    """CaTExperienceBuffer driven the way CaTA2CAgent.play_steps drives it (rl_games/cat_common.py:35-112): float dones
+    stored per step, value_bootstrap reward shaping with time-outs, discount_values on the buffer planes,
+    swap_and_flatten01 of the listed tensors - against the oracle's restatement."""
+    from cat_envs.tasks.utils.rl_games import (CaTExperienceBuffer, bootstrap_time_outs, discount_values,
+                                               swap_and_flatten01)
+    T, N, D, A = 24, 512, 45, 12
+    class Box:                                       # gym.spaces.Box stand-in: only .shape is read
+        def __init__(self, *shape):
+            self.shape = shape
+    buf = CaTExperienceBuffer({"observation_space": Box(D), "action_space": Box(A), "agents": 1, "value_size": 1},
+                              {"num_actors": N, "horizon_length": T, "has_central_value": False,
+                               "use_action_masks": False}, "cuda")
+    assert buf.tensor_dict["dones"].dtype == torch.float32 and buf.tensor_dict["dones"].shape == (T, N)
+    assert buf.tensor_dict["obses"].shape == (T, N, D) and buf.tensor_dict["values"].shape == (T, N, 1)
+    x = S.gae_inputs(77, T, N)
+    rs = np.random.RandomState(5)
+    obs = rs.standard_normal((T, N, D)).astype(np.float32)
+    time_outs = rs.rand(T, N) < 0.05
+    dones = torch.ones(N, device="cuda")             # rl_games starts with dones = 1
+    dones_seq = np.concatenate([np.ones((1, N), np.float32), x["dones"][:-1]])
+    shaped = np.zeros((T, N), np.float32)
+    for n in range(T):
+        buf.update_data("obses", n, dev(obs[n]))
+        buf.update_data("dones", n, dones)
+        buf.update_data("values", n, dev(x["values"][n])[:, None])
+        rew = dev(x["rewards"][n]).clone()[:, None]
+        bootstrap_time_outs(rew, dev(x["values"][n])[:, None], dev(time_outs[n]), 0.99)
+        buf.update_data("rewards", n, rew)
+        shaped[n] = PO.value_bootstrap(torch.from_numpy(x["rewards"][n]), torch.from_numpy(x["values"][n]),
+                                       torch.from_numpy(time_outs[n]), 0.99).numpy()
+        dones = dev(x["dones"][n])                   # float termination probability of this step
+    np.testing.assert_array_equal(buf.tensor_dict["dones"].cpu().numpy(), dones_seq)
+    np.testing.assert_array_equal(buf.tensor_dict["rewards"].cpu().numpy()[..., 0], shaped)
+    adv = discount_values(dones, dev(x["next_value"])[:, None], buf.tensor_dict["dones"], buf.tensor_dict["values"],
+                          buf.tensor_dict["rewards"], 0.99, 0.95)
+    a, r = PO.gae_rl_games(torch.from_numpy(x["dones"][-1]), torch.from_numpy(x["next_value"]),
+                           torch.from_numpy(dones_seq), torch.from_numpy(x["values"]), torch.from_numpy(shaped), 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy()[..., 0], a.numpy())
+    batch = buf.get_transformed_list(swap_and_flatten01, ["obses", "dones", "values", "not_there"])
+    assert sorted(batch) == ["dones", "obses", "values"] and batch["obses"].shape == (N * T, D)
+    np.testing.assert_array_equal(batch["obses"].cpu().numpy(), obs.transpose(1, 0, 2).reshape(N * T, D))
+    assert set(buf.get_transformed(lambda t: t)) == set(buf.tensor_dict)
+    small = CaTExperienceBuffer.from_shapes(8, 4, (3,), 2)
+    assert small.tensor_dict["actions"].shape == (4, 8, 2)
+
+
+def test_skrl_kl_adaptive_scheduler_class(nat):
+    """cat_envs.tasks.utils.skrl.KLAdaptiveLR.step(diag): the call site of skrl/ppo.py:558-567 as three device launches"""
+    from cat_envs import native
+    from cat_envs.tasks.utils.skrl import KLAdaptiveLR
+    st = nat.iter_state_new(3, 5e-4)
+    nat.iter_begin(st, 5e-4, 10, native.LR_KEEP)
+    sch = KLAdaptiveLR(st, kl_threshold=0.01)
+    diag = torch.zeros(8, device="cuda")
+    lr = 5e-4
+    for epoch, kl in enumerate([0.001, 0.001, 0.03, 0.0075, 0.5]):
+        diag[4] += kl * 4
+        diag[7] += 4
+        sch.step(diag)
+        if kl > 0.02:
+            lr = max(lr / 1.5, 1e-6)
+        elif kl < 0.005:
+            lr = min(lr * 1.5, 1e-2)
+        assert abs(sch.get_last_lr()[0] - lr) < 1e-12, (epoch, sch.get_last_lr(), lr)
+
+
 # ------------------------------------------------------------------------------------------ RCCL under the C ABI
 def test_rccl_c_abi_world_of_one_and_graph_capture():
     """catppo_comm_unique_id / _init / catppo_allreduce / _broadcast on a world of size 1 (the only world a one-GPU
