@@ -183,12 +183,25 @@ __global__ __launch_bounds__(kThreads) void rms_normalize(const XT* __restrict__
   }
 }
 
+// grid of rms_moments_partial: up to 128 workgroups (= partial rows folded afterwards); a thread walks at most 16 rows of
+// a slab, fewer when that would leave the launch with under ~96 workgroups (98304 scalars: 24 workgroups x 16 dependent
+// row loads took 19 us, 128 x 3 take a third of that)
+inline void moments_grid(int64_t N, int G, int* rows_per_block, int* nblk) {
+  int per_thread = 16;
+  if (cdiv64(N, (int64_t)G * 16) < 96) {
+    per_thread = (int)cdiv64(N, (int64_t)G * 128);
+    if (per_thread < 1) per_thread = 1;
+  }
+  *rows_per_block = G * per_thread;
+  int64_t nb = cdiv64(N, *rows_per_block);
+  *nblk = (int)(nb > 128 ? 128 : nb);
+}
+
 int launch_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, double* sums, hipStream_t s) {
   const int Dc = D < kThreads ? D : kThreads;
   const int G = kThreads / Dc;
-  const int rows_per_block = G * 16;
-  int nblk = (int)cdiv64(N, rows_per_block);
-  if (nblk > 128) nblk = 128;
+  int rows_per_block, nblk;
+  moments_grid(N, G, &rows_per_block, &nblk);
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   CATPPO_NEED_WS(ctx, partial);
@@ -259,15 +272,14 @@ extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int
   hipStream_t s = static_cast<hipStream_t>(stream);
   // the fp64 column sums live at the tail of the workspace, after the per-block partials
   const int Dc = D < kThreads ? D : kThreads;
-  int nblk = (int)cdiv64(N, (kThreads / Dc) * 16);
-  if (nblk > 128) nblk = 128;
+  int rows_per_block, nblk;
+  moments_grid(N, kThreads / Dc, &rows_per_block, &nblk);
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   double* sums = ws.take<double>((uint64_t)2 * D);
   CATPPO_NEED_WS(ctx, partial);
   CATPPO_NEED_WS(ctx, sums);
   if (2 * D <= kFusedMax) {
-    const int rows_per_block = (kThreads / Dc) * 16;
     hipLaunchKernelGGL(rms_moments_partial<float>, dim3(nblk), dim3(kThreads), 0, s, x, N, D, ldx, rows_per_block, partial);
     CATPPO_CHECK_LAUNCH(ctx);
     hipLaunchKernelGGL(rms_final_merge, dim3(1), dim3(kThreads), 0, s, (const double*)partial, nblk, (double)N, D, mean,
@@ -334,9 +346,8 @@ extern "C" int catppo_rms_moments_ex(catppo_ctx* ctx, const void* x, int x_dtype
   CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16 && x && sums && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int Dc = D < kThreads ? D : kThreads;
-  const int rows_per_block = (kThreads / Dc) * 16;
-  int nblk = (int)cdiv64(N, rows_per_block);
-  if (nblk > 128) nblk = 128;
+  int rows_per_block, nblk;
+  moments_grid(N, kThreads / Dc, &rows_per_block, &nblk);
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   CATPPO_NEED_WS(ctx, partial);
@@ -356,9 +367,8 @@ extern "C" int catppo_rms_update_ex(catppo_ctx* ctx, const void* x, int x_dtype,
   CATPPO_CHECK_ARG(ctx, x && mean && var && count && N >= 1 && D >= 1 && 2 * D <= kFusedMax && ldx >= D);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int Dc = D < kThreads ? D : kThreads;
-  const int rows_per_block = (kThreads / Dc) * 16;
-  int nblk = (int)cdiv64(N, rows_per_block);
-  if (nblk > 128) nblk = 128;
+  int rows_per_block, nblk;
+  moments_grid(N, kThreads / Dc, &rows_per_block, &nblk);
   WsCarver ws(ctx);
   double* partial = ws.take<double>((uint64_t)nblk * 2 * D);
   CATPPO_NEED_WS(ctx, partial);
