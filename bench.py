@@ -340,10 +340,14 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{a.workload}: {w['desc']}", "envs_per_gpu": trainer.N, "envs_total": env_total,
                        "horizon": w["num_steps"], "minibatch_per_gpu": M, "global_minibatch": M * world,
-                       "parallelism": f"env-sharded dp{world}, catppo_allreduce (RCCL) of the flat gradient",
+                       "parallelism": f"env-sharded dp{world}, " + ("catppo_allreduce (RCCL)" if
+                                      parallel.native_comm_active() or world == 1 else "torch.distributed all_reduce (RCCL)")
+                                      + " of the flat gradient",
                        "rccl_world": nat.comm_world if parallel.native_comm_active() else (world if world > 1 else 0),
                        "collectives": "libcatppo C ABI (librccl)" if parallel.native_comm_active() else
-                                      ("torch.distributed" if world > 1 else "none"),
+                                      ("torch.distributed" + (f" (native set-up failed: {parallel.native_comm_error()})"
+                                                              if parallel.native_comm_error() else "")
+                                       if world > 1 else "none"),
                        "timed_region": "K x run_iteration(log=True): includes the per-iteration diagnostics read-back",
                        "simulated_shard_of_world": a.shard_of if a.shard_of > 0 else None,
                        "rng": trainer.rng, "fused_rollout": trainer.sink is not None,

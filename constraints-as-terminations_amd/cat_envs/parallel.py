@@ -24,6 +24,9 @@ _FORCE = os.environ.get("CATPPO_FORCE_DIST", "0") == "1"
 _native = None
 
 
+_native_error = None
+
+
 def init_native_comm(nat, group=None) -> bool:
     """Create libcatppo's own RCCL communicator (catppo_comm_init) for the ranks of the initialised
     torch.distributed world: rank 0 makes the unique id, the launcher's process group only ships its 128 bytes.
@@ -35,11 +38,42 @@ def init_native_comm(nat, group=None) -> bool:
         return True
     if not active(group) or os.environ.get("CATPPO_NATIVE_COMM", "1") == "0":
         return False
-    box = [nat.comm_unique_id() if rank(group) == 0 else None]
+    # Every rank must end up on the same transport: a rank that could not join (librccl not loadable, communicator
+    # set-up refused) votes no, and then ALL ranks keep torch.distributed (RCCL through PyTorch) - said on stderr
+    # and in native_comm_error(), never silently.
+    global _native_error
+    err = None
+    try:
+        box = [nat.comm_unique_id() if rank(group) == 0 else None]
+    except RuntimeError as e:      # rank 0 could not even make an id: the others must not wait inside RCCL
+        box, err = [None], str(e)
     dist.broadcast_object_list(box, src=0, group=group)
-    nat.comm_init(rank(group), world_size(group), box[0])
+    if box[0] is None:
+        err = err or "rank 0 could not create an RCCL unique id"
+    else:
+        try:
+            nat.comm_init(rank(group), world_size(group), box[0])
+        except RuntimeError as e:
+            err = str(e)
+    votes = [None] * world_size(group)
+    dist.all_gather_object(votes, err, group=group)
+    failed = [(r, v) for r, v in enumerate(votes) if v is not None]
+    if failed:
+        if err is None:
+            nat.comm_destroy()
+        _native_error = "; ".join(f"rank {r}: {v}" for r, v in failed)
+        if rank(group) == 0:
+            import sys
+            print(f"[catppo] native RCCL communicator unavailable, collectives stay on torch.distributed: "
+                  f"{_native_error}", file=sys.stderr)
+        return False
     _native = nat
     return True
+
+
+def native_comm_error():
+    """why init_native_comm() fell back to torch.distributed (None when it did not)"""
+    return _native_error
 
 
 def shutdown_native_comm():

@@ -26,8 +26,13 @@ struct RcclApi {
   char why[256] = {0};
 };
 
-RcclApi* rccl() {
+RcclApi& rccl_state() {
   static RcclApi api;
+  return api;
+}
+
+RcclApi* rccl() {
+  RcclApi& api = rccl_state();
   static bool tried = false;
   if (tried) return api.handle ? &api : nullptr;
   tried = true;
@@ -57,10 +62,10 @@ RcclApi* rccl() {
   return &api;
 }
 
+// why rccl() returned nullptr
 const char* why_not() {
-  static RcclApi dummy;
-  (void)dummy;
-  return "librccl could not be loaded";
+  const RcclApi& api = rccl_state();
+  return api.why[0] ? api.why : "librccl could not be loaded";
 }
 
 int comm_fail(catppo_ctx* ctx, RcclApi* r, const char* what, ncclResult_t rc) {

@@ -137,6 +137,36 @@ def _worker(rank, world, port, out_dir):
     # no HIP device here: the native RCCL communicator is not used, torch.distributed carries the exchange
     assert not parallel.native_comm_active()
 
+    # ---- 3d. the native communicator set-up is all-or-nothing: rank 1 cannot join -> BOTH ranks keep
+    #          torch.distributed and know why; then rank 0 cannot even make an id -> same outcome, nobody hangs
+    class _Nat:
+        def __init__(self, fail_id=False, fail_init=False):
+            self.fail_id, self.fail_init, self.destroyed = fail_id, fail_init, False
+
+        def comm_unique_id(self):
+            if self.fail_id:
+                raise RuntimeError("catppo_comm_unique_id failed (-6): librccl could not be loaded")
+            return bytes(128)
+
+        def comm_init(self, r, w, uid):
+            assert len(uid) == 128 and w == world
+            if self.fail_init:
+                raise RuntimeError("libcatppo error -6: ncclCommInitRank: unhandled system error")
+
+        def comm_destroy(self):
+            self.destroyed = True
+
+    nat_a = _Nat(fail_init=(rank == 1))
+    assert parallel.init_native_comm(nat_a) is False and not parallel.native_comm_active()
+    assert "rank 1" in parallel.native_comm_error() and "rank 0" not in parallel.native_comm_error()
+    assert nat_a.destroyed == (rank == 0)          # the rank that HAD joined left again
+    nat_b = _Nat(fail_id=(rank == 0))
+    assert parallel.init_native_comm(nat_b) is False and "unique id" in parallel.native_comm_error() or \
+        "librccl" in parallel.native_comm_error()
+    chk = torch.ones(1)
+    parallel.allreduce_sum_(chk)                   # the fallback transport still works
+    assert float(chk) == world
+
     # ---- 4. broadcast of the flat parameters from rank 0
     flat = torch.full((10,), float(rank))
     parallel.broadcast_(flat, src=0)
