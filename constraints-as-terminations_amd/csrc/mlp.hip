@@ -133,6 +133,27 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
 }
 
 // ------------------------------------------------------------------------------- GEMM launch
+constexpr int kSmallRows = 4096;    // see launch_dw_dx_pair
+
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// fp32 launch with a wider contraction slab (latency-bound small-M launches: fewer global round trips per tile)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT>
+void launch_gemm_bk(const Params& p, hipStream_t s) {
+  dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);
+  constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC, BKT>();
+  auto kern = gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, BKT>;
+  if (lds > 64 * 1024) {
+    static const hipError_t once =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)once;
+  }
+  kern<<<grid, dim3(256), lds, s>>>(p);
+}
+
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
 void launch_gemm(const Params& p, hipStream_t s, int prec, size_t lds_pad = 0) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);   // 1-D tile index, see kernel
@@ -185,10 +206,19 @@ void launch_gemm_auto(const Params& p, hipStream_t s, int prec) {
       return;
     }
   }
-  if (use_big)
+  if (use_big) {
     launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, prec);
-  else
-    launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, prec);
+    return;
+  }
+  if constexpr (EPI != gemm::EPI_PARTIAL) {
+    static const int small_bk = env_int("CATPPO_SMALL_BK", 64);      // 16 | 32 | 64, see kSmallRows
+    if (prec == 0 && small_bk > 16 && p.I <= kSmallRows && p.Kc % small_bk == 0 && p.Kc >= 2 * small_bk) {
+      if (small_bk == 32) launch_gemm_bk<64, 64, A_KC, B_KC, EPI, 32>(p, s);
+      else launch_gemm_bk<64, 64, A_KC, B_KC, EPI, 64>(p, s);
+      return;
+    }
+  }
+  launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, prec);
 }
 
 template <int BM, int BN>
@@ -215,8 +245,15 @@ void launch_pair_tiles(const Params& pw, const Params& px, hipStream_t s, int pr
         <<<dim3(n0 + n1), dim3(256), lds, s>>>(pw, px, t0, n0, t1);
 }
 
+// Minibatches of at most kSmallRows rows leave every CU with one or two workgroups: each wave is alone on its SIMD and
+// every contraction slab costs a full global round trip.  There the weight gradient runs on 64x64 tiles (4x the
+// workgroups of the 128x128 choice: 2048 rows, 256x512 layer: 35 -> 27 us for the pair) and the forward GEMMs walk
+// the contraction in 64-wide slabs (4x fewer round trips; 112 -> 100 us per optimiser step together; measured with
+// CATPPO_DW_SMALL_TILE / CATPPO_SMALL_BK, which remain as switches).
 void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, int prec) {
-  const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256;   // launch_gemm_auto's rule for EPI_PARTIAL
+  static const int small_tile = env_int("CATPPO_DW_SMALL_TILE", 1);
+  const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256 &&   // launch_gemm_auto's rule for EPI_PARTIAL
+                   !(px.I <= kSmallRows && small_tile);
   const bool wide = px.J >= 128;
   if (big && wide) launch_pair_tiles<128, 128, 64, 128>(pw, px, s, prec);
   else if (big) launch_pair_tiles<128, 128, 64, 64>(pw, px, s, prec);
