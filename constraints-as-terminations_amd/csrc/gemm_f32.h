@@ -64,6 +64,10 @@ __device__ __forceinline__ float elu_f(float z) {
   return z > 0.0f ? z : e;
 }
 
+#ifdef GEMM_TIMELINE   // tools/pair_timeline.hip: per-workgroup stamps [1] main loop start, [2] main loop end (shader clocks)
+__device__ unsigned long long* g_tl;
+#endif
+
 // One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
 // (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0>
@@ -207,6 +211,9 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
       }
   }
 
+#ifdef GEMM_TIMELINE
+  if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 1] = clock64();
+#endif
   for (int s = 0; s < n_slabs; ++s) {
     const int cur = s & 1;
     if (s + 1 < n_slabs) gload(k_begin + (s + 1) * BK);
@@ -323,6 +330,9 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
     __syncthreads();
   }
 
+#ifdef GEMM_TIMELINE
+  if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 2] = clock64();
+#endif
   // ---- epilogue.  acc[tm][tn][r] of lane: row = (r&3) + 8*(r>>2) + 4*h, col = l31 ----------
   float* Cout = op.C;
   if (EPI == EPI_PARTIAL) Cout += (int64_t)split * p.c_split_stride;

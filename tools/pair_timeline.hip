@@ -4,6 +4,7 @@
 // ceiling and shader clock.  Build here, run on the GPU box (the binary travels with the snapshot):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/pair_timeline.hip -o tools/bin/pair_timeline
 // Findings of round 2 are in DESIGN.md section 4 ("Where the paired launch spends its time").
+#define GEMM_TIMELINE
 #include "../constraints-as-terminations_amd/csrc/gemm_f32.h"
 
 #include <algorithm>
@@ -132,6 +133,38 @@ void variant(const char* name, Params pw, Params px, int splits, int order, int 
          pct(end0, 1.0), pct(end1, 0.1), pct(end1, 0.5), pct(end1, 0.9), pct(end1, 1.0));
 }
 
+void fwd(const char* name, const Params& p) {
+  auto kern = gemm::gemm_f32_kernel<128, 128, true, true, gemm::EPI_BIAS_ELU>;
+  dim3 grid(((p.J + 127) / 128) * ((p.I + 127) / 128), 1, p.nets);
+  const int nwg = grid.x * grid.z;
+  const size_t lds = gemm::smem_bytes<128, 128, true, true>();
+  unsigned long long* tl;
+  CK(hipMalloc(&tl, (size_t)nwg * 4 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(gemm::g_tl), &tl, sizeof(tl)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) kern<<<grid, 256, lds>>>(p);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 20; ++i) kern<<<grid, 256, lds>>>(p);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)nwg * 4);
+  CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+  double loop0 = 0, loop1 = 0;
+  for (unsigned b = 0; b < grid.x; ++b) {
+    loop0 += h[4 * b + 2] - h[4 * b + 1];
+    loop1 += h[4 * (b + grid.x) + 2] - h[4 * (b + grid.x) + 1];
+  }
+  const double sc = 1.0 / grid.x / 2390.0;
+  printf("%-34s %.1f us/launch | main loop: net 0 workgroups %.1f us, net 1 workgroups %.1f us\n", name,
+         ms * 1e3f / 20, loop0 * sc, loop1 * sc);
+  CK(hipFree(tl));
+}
+
 // Empirical fp32-MFMA ceiling: every wave issues independent v_mfma_f32_32x32x2_f32 back to back, no memory traffic.
 __global__ __launch_bounds__(256) void mfma_peak(float* out, int iters, unsigned long long* clk) {
   gemm::f32x16 acc[4];
@@ -208,17 +241,14 @@ int main() {
     pw.op[n].dbias = dbp + (size_t)n * 128 * H;
     px.op[n].A = dZ[n], px.op[n].B = W[n], px.op[n].C = dX[n], px.op[n].aux = Hin[n];
   }
-  for (int round = 0; round < 3; ++round) {     // round 0 runs on a cold clock: read rounds 1-2
-    printf("---- round %d\n", round);
-    variant<128, 128, 64, 128>("A production: dW first, s32", pw, px, 32, 0, 0, 0, drec);
-    variant<128, 128, 64, 128>("B dW last", pw, px, 32, 1, 0, 0, drec);
-    variant<128, 128, 64, 128>("C dW every 5th workgroup", pw, px, 32, 2, 5, 0, drec);
-    variant<128, 128, 64, 128>("D dW s64", pw, px, 64, 0, 0, 0, drec);
-    variant<128, 128, 64, 128>("E dW s32 + dX 2 tiles/wg", pw, px, 32, 0, 0, 0, drec, 2);
-    variant<128, 128, 64, 128>("F dW s64 + dX 2 tiles/wg (uniform)", pw, px, 64, 0, 0, 0, drec, 2);
-    variant<128, 128, 64, 128, 4>("G = A at 4 waves/SIMD (128 VGPRs)", pw, px, 32, 0, 0, 0, drec);
-    variant<128, 128, 64, 128, 4>("H = E at 4 waves/SIMD", pw, px, 32, 0, 0, 0, drec, 2);
-    variant<128, 128, 128, 128>("I dX 128x128", pw, px, 32, 0, 0, 0, drec);
+  {
+    Params pf{};
+    float* bias;
+    CK(hipMalloc(&bias, 4096));
+    CK(hipMemset(bias, 0, 4096));
+    pf.nets = 2, pf.splits = 1, pf.I = M, pf.J = H, pf.Kc = H, pf.lda = H, pf.ldb = H, pf.ldc = H;
+    for (int n = 0; n < 2; ++n) pf.op[n].A = Hin[n], pf.op[n].B = W[n], pf.op[n].C = dX[n], pf.op[n].bias = bias;
+    for (int r = 0; r < 3; ++r) fwd("forward 128x128", pf);
   }
   return 0;
 }
