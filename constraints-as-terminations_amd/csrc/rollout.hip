@@ -25,6 +25,15 @@
 namespace {
 
 using namespace terms;
+// -DROLLOUT_TL (tools/rollout_timeline.py): thread 0 of every workgroup stamps the wall clock (100 MHz) at the phase
+// boundaries of the two kernels into a buffer set through catppo_debug_rollout_tl().  Compiles away otherwise.
+#ifdef ROLLOUT_TL
+__device__ unsigned long long* g_rtl;     // [2 kernels][1024 workgroups][16 stamps]
+#define RL_TL(k, i) do { if (threadIdx.x == 0 && g_rtl) g_rtl[((k) * 1024 + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define RL_TL(k, i) do { } while (0)
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kPostRows = 32;
 constexpr int kMaxObsPerThread = 2;     // D <= 512
@@ -126,6 +135,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   __shared__ int s_ids[kMaxTerms][CATPPO_TERM_MAX_IDS];
   const int K = a.K, A = a.A, D = a.D;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  RL_TL(0, 0);
   for (int c = threadIdx.x; c < K; c += kThreads) cmax[c] = -__builtin_inff();
   for (int o = threadIdx.x; o < tab.n * CATPPO_TERM_MAX_IDS; o += kThreads)
     s_ids[o / CATPPO_TERM_MAX_IDS][o % CATPPO_TERM_MAX_IDS] = tab.d[o / CATPPO_TERM_MAX_IDS].ids[o % CATPPO_TERM_MAX_IDS];
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   for (int q = 0; q < kMaxObsPerThread; ++q) os1[q] = 0.0, os2[q] = 0.0;
 
   const int64_t n_tiles = (a.N + kRows - 1) / kRows;
+  RL_TL(0, 1);
   for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
     const int64_t r0 = tl * kRows;
     const int rows = (int)((a.N - r0) < kRows ? (a.N - r0) : kRows);
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
         tile[e * K + col0 + j] = eval_term(d, s_ids[t], r0 + e, j, a.forces, a.fstride, a.H, a.B, a.command, a.cld);
       }
     }
+    RL_TL(0, 9);
     // ---- counters, terminations, raw reward (cat_env.py:92-97)
     if (threadIdx.x < rows) {
       const int64_t i = r0 + threadIdx.x;
@@ -165,6 +177,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
       a.reset[i] = to || term;
       a.reward[i] = a.reward_src[i * a.rw_stride];
     }
+    RL_TL(0, 10);
     // ---- observation moments of the tile (fp64, fixed order)
     if (a.obs_raw != nullptr && og < OG) {
 #pragma unroll
@@ -190,7 +203,9 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
         }
       }
     }
+    RL_TL(0, 11);
     __syncthreads();
+    RL_TL(0, 12);
     // ---- flush the tile, running column maxima, and only now shift the action history (process_action)
     float* dst = a.cstr + r0 * K;
     for (int e = threadIdx.x; e < rows * K; e += kThreads) dst[e] = tile[e];
@@ -206,6 +221,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
     }
     __syncthreads();
   }
+  RL_TL(0, 2);
   for (int c = threadIdx.x; c < K; c += kThreads) a.colmax_partial[(int64_t)blockIdx.x * K + c] = cmax[c];
   if (a.obs_raw != nullptr) {
     // combine the row groups of the block in ascending g (fixed order), one partial row per block
@@ -230,14 +246,20 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   const int nblk = gridDim.x;
   const int grp = blockIdx.x / kFoldGroup, n_grp = (nblk + kFoldGroup - 1) / kFoldGroup;
   const int g0 = grp * kFoldGroup, g_rows = (nblk - g0) < kFoldGroup ? (nblk - g0) : kFoldGroup;
-  if (!last_block_arrives(a.ticket + 1 + grp, (unsigned)g_rows)) return;
+  RL_TL(0, 3);
+  const bool last1 = last_block_arrives(a.ticket + 1 + grp, (unsigned)g_rows);
+  RL_TL(0, 4);
+  if (!last1) return;
   block_fold<float>(a.colmax_partial + (int64_t)g0 * K, g_rows, K, -__builtin_inff(),
                     [](float x, float y) { return nanmax(x, y); }, reinterpret_cast<float*>(fold_lds),
                     [&](int c, float m) { a.colmax_group[(int64_t)grp * K + c] = m; });
   if (a.obs_raw != nullptr)
     block_fold<double>(a.osum_partial + (int64_t)g0 * 2 * D, g_rows, 2 * D, 0.0, [](double x, double y) { return x + y; },
                        fold_lds, [&](int c, double v) { a.osum_group[(int64_t)grp * 2 * D + c] = v; });
-  if (!last_block_arrives(a.ticket, (unsigned)n_grp)) return;
+  RL_TL(0, 5);
+  const bool last2 = last_block_arrives(a.ticket, (unsigned)n_grp);
+  RL_TL(0, 6);
+  if (!last2) return;
   block_fold<float>(a.colmax_group, n_grp, K, -__builtin_inff(), [](float x, float y) { return nanmax(x, y); },
                     reinterpret_cast<float*>(fold_lds), [&](int c, float m) {
                       a.x_colmax[c] = (m < 1e-6f) ? 1e-6f : m;      // clamp(min=1e-6); NaN stays NaN like torch
@@ -245,6 +267,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   if (a.obs_raw != nullptr)
     block_fold<double>(a.osum_group, n_grp, 2 * D, 0.0, [](double x, double y) { return x + y; }, fold_lds,
                        [&](int c, double v) { a.x_sums[c] = v; });
+  RL_TL(0, 7);
 }
 
 struct TermMetaS {
@@ -312,6 +335,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
   __shared__ int s_off[kMaxTerms + 1];
   __shared__ float s_tot;
 
+  RL_TL(1, 0);
   if (threadIdx.x <= nt) s_off[threadIdx.x] = meta.off[threadIdx.x];
   __syncthreads();
   // ---- new running maxima (constraint_manager.py:58-61), identical in every workgroup
@@ -361,6 +385,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     }
   }
   __syncthreads();
+  RL_TL(1, 1);
 
   const int64_t r0 = (int64_t)blockIdx.x * kPostRows;
   const int rows = (int)((a.N - r0) < kPostRows ? (a.N - r0) : kPostRows);
@@ -453,7 +478,10 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
       a.obs_out[(r0 + r) * a.obs_out_ld + c] = v / s_den[c];
     }
   }
-  if (!last_block_arrives(a.ticket, gridDim.x)) return;
+  RL_TL(1, 2);
+  const bool lastp = last_block_arrives(a.ticket, gridDim.x);
+  RL_TL(1, 3);
+  if (!lastp) return;
   // ---- last workgroup: publish the new state, fold the reset statistics
   for (int c = threadIdx.x; c < K; c += kThreads) a.rm[c] = col_rm[c];
   if (a.obs_raw != nullptr) {
@@ -473,7 +501,15 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
                          else if (a.log_prev != nullptr) a.log_out[c] = a.log_prev[c];
                        });
   }
+  RL_TL(1, 4);
 }
+
+#ifdef ROLLOUT_TL
+extern "C" int catppo_debug_rollout_tl(void* buf) {     // timeline builds only: not part of include/catppo.h
+  unsigned long long* p = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_rtl), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 inline uint64_t xchg_sum_offset(int K) { return ((uint64_t)K * sizeof(float) + 15) / 16 * 16; }
 
