@@ -35,7 +35,9 @@ enum Epilogue {
   EPI_BIAS_ELU = 0,  // C = elu(acc + bias[j])                       forward hidden layer
   EPI_MUL_DELU = 1,  // C = acc * elu'(aux[i,j]) (aux = activation)  data gradient
   EPI_PARTIAL = 2,   // C[split] = acc (+ column sums of A -> dbias) weight gradient, split-K
+  EPI_BIAS_ELU_LDS = 3,  // elu(acc + bias[j]) left in LDS as a [BM][BN + kLdsTilePad] tile for a fused consumer
 };
+constexpr int kLdsTilePad = 4;    // row stride BN + 4 floats: a b128 read by 16 consecutive rows hits 16 distinct 16-B slots
 
 struct Operands {
   const float* A;
@@ -68,6 +70,14 @@ __device__ __forceinline__ float elu_f(float z) {
 __device__ unsigned long long* g_tl;
 #endif
 
+// XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, each XCD has a private L2.  Give every XCD a
+// contiguous range of the tile sequence, so the tiles that share an operand row block hit the same L2 instead of
+// fetching it once per XCD through the fabric.  Bijective for any workgroup count.
+__device__ __forceinline__ int xcd_tile_index(int wg, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+}
+
 // One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
 // (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0>
@@ -90,15 +100,8 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
   const int net = bz % p.nets;
   const int split = bz / p.nets;
   const Operands op = p.op[net];   // by value: pointers live in SGPRs for the whole kernel
-  // XCD-aware tile order (speed only): workgroup b runs on XCD b % 8, each XCD has a private L2.  Give
-  // every XCD a contiguous range of the tile sequence (j fastest), so the tiles that share an A row
-  // block hit the same L2 instead of fetching it once per XCD through the fabric.
   const int tiles_j = (p.J + BN - 1) / BN;
-  int wg = wg_raw;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-  }
+  const int wg = xcd_tile_index(wg_raw, nwg);     // j fastest within an XCD's range
   const int i0 = (wg / tiles_j) * BM;
   const int j0 = (wg % tiles_j) * BN;
   const int tid = threadIdx.x;
@@ -334,6 +337,24 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
   if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 2] = clock64();
 #endif
   // ---- epilogue.  acc[tm][tn][r] of lane: row = (r&3) + 8*(r>>2) + 4*h, col = l31 ----------
+  if constexpr (EPI == EPI_BIAS_ELU_LDS) {
+    // the activated tile stays on chip, over the slab buffers (free after the loop's last barrier); the caller
+    // synchronises before reading it.  Rows past p.I hold elu(bias): the consumer masks them.
+    constexpr int LD = BN + kLdsTilePad;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int cj = wn * WN + tn * 32 + l31;
+        const float bias = j0 + cj < p.J ? op.bias[j0 + cj] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int lrow = wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          smem[lrow * LD + cj] = elu_f(acc[tm][tn][r] + bias);
+        }
+      }
+    return;
+  }
   float* Cout = op.C;
   if (EPI == EPI_PARTIAL) Cout += (int64_t)split * p.c_split_stride;
   // Activation-sized outputs (forward, data gradient) leave through LDS: a lane owns one COLUMN of a 32x32

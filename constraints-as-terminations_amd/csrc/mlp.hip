@@ -263,8 +263,9 @@ void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, int pr
 
 // hidden-layer forward for `nets` networks starting at net index net0
 void forward_hidden(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, const float* params, const float* x,
-                    int64_t M, const MlpWs& w, int net0, int nets, hipStream_t s) {
-  for (int l = 0; l < sh->n_hidden; ++l) {
+                    int64_t M, const MlpWs& w, int net0, int nets, hipStream_t s, int n_layers = -1) {
+  if (n_layers < 0) n_layers = sh->n_hidden;
+  for (int l = 0; l < n_layers; ++l) {
     Params p{};
     p.nets = nets;
     p.splits = 1;
@@ -791,6 +792,325 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
   for (int o = tid; o < NS; o += NT) ps[o] = ls[o];
 }
 
+// ------------------------------------------------------------------------------- last hidden layer + heads + loss
+// One launch instead of the last forward GEMM followed by head_loss_kernel (28 us at M = 16384 with no matrix work,
+// 33 MB of last-layer activations written and read back): a workgroup owns 64 rows of ONE network over the full
+// last-layer width, leaves H = elu(X W^T + b) in LDS (gemm::EPI_BIAS_ELU_LDS) and runs that network's head, its part
+// of the PPO loss and the backward through the head on the tile.  The three head products are small GEMMs on the
+// same fp32 MFMA (16 head outputs, rows past the real count zero):
+//   A  Y[64,16]   = H[64,HL] . Wh^T          each wave a quarter of the contraction, quarters added in fixed order
+//   -  row math   one thread per row: log-prob / ratio / clipped surrogate / d loss/d mu, or value loss / d loss/d v
+//                 (the arithmetic of head_loss_kernel, ppo.py:299-345) -> G[64,16]
+//   C  dWh[16,HL] = G^T . H                  contraction over the 64 rows; per-workgroup partial
+//   B  dZ[64,HL]  = (G . Wh) * elu'(H)       written over H in LDS, then streamed out as whole rows
+// Partial rows [0, RB) belong to the actor workgroups, [RB, 2 RB) to the critic's (row layout of head_loss_kernel,
+// each kind writes only its own entries; the fold reads them with separate base pointers).
+template <int HL>
+constexpr size_t fwd_head_lds_floats() { return (size_t)64 * (HL + gemm::kLdsTilePad) + 64 * 16 + 64 * 16 + 64 * 8 + 4; }
+
+template <int HL>
+__global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const HeadArgs g) {
+  using gemm::f32x16;
+  constexpr int BM = 64, LD = HL + gemm::kLdsTilePad;
+  constexpr int KQ = HL / 4;            // contraction share of a wave in step A
+  constexpr int TNB = HL / 64;          // 32-column tiles per wave in step B (waves 2 x 2)
+  constexpr int TNC = HL / 128;         // 32-column tiles per wave in step C (waves 1 x 4)
+  constexpr int NCH = HL / 4;           // float4 chunks per row (copy-out)
+  constexpr int RG = 256 / NCH;         // row groups (copy-out)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Hs = smem;                     // [64][LD]   activated tile, later dZ
+  float* sG = Hs + BM * LD;             // [64][16]   d loss / d head output k of row r (zero beyond the real outputs)
+  float* sMu = sG + BM * 16;            // [64][16]   head outputs, later the per-row d loss / d logstd_k terms
+  float* sD = sMu + BM * 16;            // [64][8]    per-row diagnostics {pg, v, ent, -, kl, old_kl, clipfrac, -}
+  float* s_adv = sD + BM * 8;           // [2]        advantage mean, std + 1e-8
+  const int net = blockIdx.z;           // 0 critic, 1 actor (Params::op order)
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int A = g.A;
+  const int RB = gridDim.x;
+  const int tile = gemm::xcd_tile_index(blockIdx.x, gridDim.x);
+  const int64_t i0 = (int64_t)tile * BM;
+  const int rows = (int)((g.M - i0) < BM ? (g.M - i0) : BM);
+  const int NS = 2 * A + 1 + kHeadDiag;
+
+  if (net == 1 && tid < 64) {           // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
+    if (g.hp.norm_adv && g.adv_stats == nullptr) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int b = lane; b < g.n_adv_part; b += 64) {
+        a1 += g.adv_part[2 * b];
+        a2 += g.adv_part[2 * b + 1];
+      }
+      a1 = wave_sum_d(a1);
+      a2 = wave_sum_d(a2);
+      if (lane == 0) {
+        const double n = (double)g.M;
+        const double mean = a1 / n;
+        double var = (a2 - n * mean * mean) / (n - 1.0);   // NaN for n == 1, like torch.std()
+        if (var < 0.0) var = 0.0;
+        s_adv[0] = (float)mean;
+        s_adv[1] = (float)sqrt(var) + 1e-8f;
+      }
+    } else if (lane == 0) {
+      s_adv[0] = g.adv_stats ? g.adv_stats[0] : 0.0f;
+      s_adv[1] = g.adv_stats ? g.adv_stats[1] : 1.0f;
+    }
+  }
+
+  const float* Wh = net == 1 ? g.W4a : g.W4c;          // [KH][HL] head weights of this network
+  const int KH = net == 1 ? A : 1;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int wm = q >> 1, wn = q & 1;
+  // Everything the epilogue reads from global memory is requested here, ahead of the main loop: the head weights in
+  // the operand layouts of steps A and B (rows past KH zero) and the gathered scalars of the row this thread will
+  // work on (row math: four threads per row, thread part pp owns the action dims pp, pp+4, pp+8, pp+12).
+  float4 bw[KQ / 8];
+#pragma unroll
+  for (int kb = 0; kb < KQ / 8; ++kb)
+    bw[kb] = l31 < KH ? *reinterpret_cast<const float4*>(Wh + l31 * HL + q * KQ + 8 * kb + 4 * h) : zero4;
+  float bwB[TNB][2][4];
+#pragma unroll
+  for (int tn = 0; tn < TNB; ++tn)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int sx = 0; sx < 4; ++sx) {
+        const int kk = 8 * blk + 4 * h + sx;
+        bwB[tn][blk][sx] = kk < KH ? Wh[kk * HL + wn * (HL / 2) + 32 * tn + l31] : 0.0f;
+      }
+  const int rr = tid >> 2, pp = tid & 3;               // row math: row, part
+  const bool rvalid = rr < rows;
+  const int64_t ri = i0 + (rvalid ? rr : 0);
+  const float rs0 = net == 1 ? g.oldlogp[ri] : g.ret_n[ri];
+  const float rs1 = net == 1 ? g.adv[ri] : g.val_n[ri];
+  float ract[4], rls[4], rb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int k = pp + 4 * kk;
+    const bool on = net == 1 && k < A;
+    ract[kk] = on ? g.act[ri * A + k] : 0.0f;
+    rls[kk] = on ? g.logstd[k] : 0.0f;
+    rb[kk] = on ? g.b4a[k] : 0.0f;
+  }
+  const float rbc = g.b4c[0], rvv = g.vrms_var[0], rvm = g.vrms_mean[0];
+
+  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+
+  // ---- A: head outputs.  MFMA step (blk, s) of lane-half h contracts k = 8 blk + 4 h + s - the same permutation on
+  //         both operands (gemm_body's K-contiguous fragments)
+  {
+    __syncthreads();                                     // H tile complete
+    f32x16 c0, c1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c0[r] = 0.0f, c1[r] = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < KQ / 8; ++kb) {
+      const float4 a0 = *reinterpret_cast<const float4*>(Hs + l31 * LD + q * KQ + 8 * kb + 4 * h);
+      const float4 a1 = *reinterpret_cast<const float4*>(Hs + (32 + l31) * LD + q * KQ + 8 * kb + 4 * h);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bw[kb].x, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bw[kb].x, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bw[kb].y, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bw[kb].y, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, bw[kb].z, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, bw[kb].z, c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bw[kb].w, c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bw[kb].w, c1, 0, 0, 0);
+    }
+    for (int w = 0; w < 4; ++w) {                        // the four contraction quarters, added in fixed order
+      if (q == w && l31 < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+          float* d0 = sMu + row * 16 + l31;
+          float* d1 = sMu + (32 + row) * 16 + l31;
+          *d0 = (w == 0 ? 0.0f : *d0) + c0[r];
+          *d1 = (w == 0 ? 0.0f : *d1) + c1[r];
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
+  // ---- row math: four threads per row
+  {
+    const int r = rr;
+    float dg[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[e] = 0.0f;
+    float gm[4] = {0.f, 0.f, 0.f, 0.f}, gl[4] = {0.f, 0.f, 0.f, 0.f};
+    if (net == 1) {
+      float diff[4], var[4];
+      float lp = 0.0f, en = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int k = pp + 4 * kk;
+        diff[kk] = 0.0f, var[kk] = 1.0f;
+        if (k < A) {
+          const float sd = expf(rls[kk]);
+          const float lsd = logf(sd);
+          var[kk] = sd * sd;
+          const float mu = sMu[r * 16 + k] + rb[kk];
+          diff[kk] = ract[kk] - mu;
+          lp += -(diff[kk] * diff[kk]) / (2.0f * var[kk]) - lsd - kHalfLog2Pi;
+          en += kEntConst + lsd;
+        }
+      }
+      lp += __shfl_xor(lp, 1, 64), en += __shfl_xor(en, 1, 64);      // the four parts of a row sit in adjacent lanes
+      lp += __shfl_xor(lp, 2, 64), en += __shfl_xor(en, 2, 64);
+      if (rvalid) {
+        const float adv_mean = s_adv[0], adv_den = s_adv[1];
+        const bool norm_adv = g.hp.norm_adv != 0;
+        const float ent_coef_m = g.hp.ent_coef * invM;
+        const float logratio = lp - rs0;
+        const float ratio = expf(logratio);
+        dg[5] = -logratio;
+        dg[4] = (ratio - 1.0f) - logratio;
+        dg[6] = fabsf(ratio - 1.0f) > clipc ? 1.0f : 0.0f;
+        const float adv = norm_adv ? (rs1 - adv_mean) / adv_den : rs1;
+        const float rc = ratio < 1.0f - clipc ? 1.0f - clipc : (ratio > 1.0f + clipc ? 1.0f + clipc : ratio);
+        const float pg1 = -adv * ratio, pg2 = -adv * rc;
+        const bool inside = ratio >= 1.0f - clipc && ratio <= 1.0f + clipc;
+        // d max(pg1,pg2) / d ratio   (torch.max splits ties 1/2 : 1/2; clamp passes gradient inside only)
+        const float dr_tie = 0.5f * -adv + (inside ? 0.5f * -adv : 0.0f);
+        const float dr = pg1 > pg2 ? -adv : (pg1 < pg2 ? (inside ? -adv : 0.0f) : dr_tie);
+        dg[0] = pg1 > pg2 ? pg1 : pg2;
+        dg[2] = en;
+        const float g_logp = dr * ratio * invM;      // d loss / d newlogprob_i
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (pp + 4 * kk < A) {
+            gm[kk] = g_logp * diff[kk] / var[kk];                                    // d loss / d mu_ik
+            gl[kk] = g_logp * (diff[kk] * diff[kk] / var[kk] - 1.0f) - ent_coef_m;   // row's share of d loss / d logstd_k
+          }
+        }
+      }
+    } else if (rvalid && pp == 0) {
+      const bool clip_vloss = g.hp.clip_vloss != 0;
+      const float vden = sqrtf(rvv + 1e-8f), vmean = rvm;
+      const float vf_half = g.hp.vf_coef * 0.5f;
+      const float R = rs0, Vo = rs1;
+      const float v = sMu[r * 16] + rbc;
+      const float nv = (v - vmean) / vden;         // value_rms(newvalue, update=False)
+      const float e1 = nv - R;
+      const float vl1 = e1 * e1;
+      const float dl = nv - Vo;
+      const float cl = dl < -clipc ? -clipc : (dl > clipc ? clipc : dl);
+      const float e2 = (Vo + cl) - R;
+      const float vl2 = e2 * e2;
+      const bool in2 = dl >= -clipc && dl <= clipc;
+      const float dnv_c = vl1 > vl2 ? 2.0f * e1 : (vl1 < vl2 ? (in2 ? 2.0f * e2 : 0.0f) : e1 + (in2 ? e2 : 0.0f));
+      const float vl = clip_vloss ? (vl1 > vl2 ? vl1 : vl2) : vl1;
+      const float dnv = clip_vloss ? dnv_c : 2.0f * e1;
+      dg[1] = 0.5f * vl;
+      gm[0] = vf_half * dnv * invM / vden;         // d loss / d v_i  (slot 0)
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) sG[r * 16 + pp + 4 * kk] = gm[kk], sMu[r * 16 + pp + 4 * kk] = gl[kk];
+    if (pp == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sD[r * 8 + e] = dg[e];
+    }
+  }
+  __syncthreads();
+
+  // ---- C: head weight gradient of the tile, dWh[k][c] = sum_r G[r][k] H[r][c]; wave q owns TNC column tiles
+  const int prow = net == 1 ? tile : RB + tile;
+  {
+    f32x16 cc[TNC];
+#pragma unroll
+    for (int t = 0; t < TNC; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cc[t][r] = 0.0f;
+    const int col0 = q * (HL / 4);
+#pragma unroll 4
+    for (int s = 0; s < BM / 2; ++s) {
+      const int r = 2 * s + h;
+      const float a = l31 < 16 ? sG[r * 16 + l31] : 0.0f;
+#pragma unroll
+      for (int t = 0; t < TNC; ++t)
+        cc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Hs[r * LD + col0 + 32 * t + l31], cc[t], 0, 0, 0);
+    }
+    float* pw = g.part_w + (int64_t)prow * (A + 1) * HL + (net == 1 ? 0 : (int64_t)A * HL);   // rows 0..A-1 = dW4a, row A = dW4c
+#pragma unroll
+    for (int t = 0; t < TNC; ++t)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {                      // accumulator rows 0..15 = head outputs
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (k < KH) pw[k * HL + col0 + 32 * t + l31] = cc[t][r];
+      }
+  }
+  __syncthreads();                                       // every read of H is done: step B overwrites it
+
+  // ---- B: dZ = (G . Wh) * elu'(H), in place
+  {
+    f32x16 cb[TNB];
+#pragma unroll
+    for (int tn = 0; tn < TNB; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cb[tn][r] = 0.0f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const float4 a4 = *reinterpret_cast<const float4*>(sG + (32 * wm + l31) * 16 + 8 * blk + 4 * h);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int tn = 0; tn < TNB; ++tn)
+          cb[tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bwB[tn][blk][s], cb[tn], 0, 0, 0);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TNB; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float* hp = Hs + row * LD + wn * (HL / 2) + 32 * tn + l31;
+        const float hv = *hp;
+        *hp = cb[tn][r] * (hv > 0.0f ? 1.0f : hv + 1.0f);      // elu'(z) = 1 (z>0) | elu(z) + 1
+      }
+  }
+  __syncthreads();
+  {
+    const int cc = tid % NCH, rg = tid / NCH;
+    float* dZ = net == 1 ? g.dZa : g.dZc;
+    for (int r = rg; r < rows; r += RG) {
+      const float4 v = *reinterpret_cast<const float4*>(Hs + r * LD + 4 * cc);
+      const float o[4] = {v.x, v.y, v.z, v.w};
+      store_vec_wt<4>(dZ + (i0 + r) * HL + 4 * cc, o);
+    }
+  }
+  // ---- scalars of the tile: bias / logstd gradients, diagnostics.  16 row groups of 4 rows, combined in fixed order
+  //      through LDS (the H / dZ tile is free again once every row has been streamed out)
+  __syncthreads();
+  {
+    float* red = Hs;                                    // [16 groups][40]: 16 db, 16 dlogstd, 8 diag
+    const int k = tid & 15, grp = tid >> 4;
+    float db = 0.0f, dl = 0.0f, dd = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * grp + j;
+      db += sG[r * 16 + k], dl += sMu[r * 16 + k];
+      if (k < 8) dd += sD[r * 8 + k];
+    }
+    red[grp * 40 + k] = db, red[grp * 40 + 16 + k] = dl;
+    if (k < 8) red[grp * 40 + 32 + k] = dd;
+  }
+  __syncthreads();
+  float* ps = g.part_s + (int64_t)prow * NS;
+  if (tid < 40) {
+    float v = 0.0f;
+#pragma unroll
+    for (int grp = 0; grp < 16; ++grp) v += Hs[grp * 40 + tid];
+    if (tid < 16) {
+      if (net == 1) { if (tid < A) ps[tid] = v; }          // db4a[k]
+      else if (tid == 0) ps[A] = v;                        // db4c
+    } else if (tid < 32) {
+      if (net == 1 && tid - 16 < A) ps[A + 1 + tid - 16] = v;   // dlogstd[k]
+    } else {
+      ps[2 * A + 1 + tid - 32] = v;                        // diagnostics
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------- segmented partial reduction
 // dst[e] (+)= scale * sum_{p<n_parts} src[p*stride + e]   in fixed order.  One launch handles every segment
 // (all split-K weight/bias partials, the head partials and the diagnostics).
@@ -1119,7 +1439,51 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const int head_cap = 2 * head_lds > 160 * 1024 ? kHeadMaxBlocks / 2 : kHeadMaxBlocks;
   if (nbh > head_cap) nbh = head_cap;
 
-  {
+  // Large fp32 minibatches: the last hidden layer, the heads, the loss and the backward through the heads are ONE
+  // launch (fwd_head_kernel).  Needs the full last-layer width in one tile (128 or 256 columns), a 16-aligned
+  // contraction, and enough 64-row tiles to fill the chip (otherwise the 64x64-tile GEMM + head_loss pair has more
+  // workgroups).  CATPPO_FUSED_HEAD=0 keeps the two launches.
+  static const int fused_head_env = env_int("CATPPO_FUSED_HEAD", 1);
+  const int RB = (int)cdiv64(M, 64);
+  const bool fused_head = fused_head_env && shape->mfma_bf16 == 0 && (HL == 128 || HL == 256) && nl >= 2 &&
+                          L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= 256 && A <= 15;
+  if (fused_head) {
+    forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
+    CATPPO_CHECK_LAUNCH(ctx);
+    Params p{};
+    p.nets = 2, p.splits = 1;
+    p.I = (int)M, p.J = HL, p.Kc = L.in_dim[nl - 1];
+    p.lda = p.Kc, p.ldb = p.Kc, p.ldc = HL;
+    for (int net = 0; net < 2; ++net) {
+      p.op[net].A = w.H[net][nl - 2];
+      p.op[net].B = params + L.off_w[net][nl - 1];
+      p.op[net].bias = params + L.off_b[net][nl - 1];
+      p.op[net].C = nullptr;              // the activations of the last layer never leave the CU
+    }
+    HeadArgs g{};
+    g.dZc = w.dZ[0][nl - 1], g.dZa = w.dZ[1][nl - 1];
+    g.W4c = params + L.off_w[0][nl], g.b4c = params + L.off_b[0][nl];
+    g.W4a = params + L.off_w[1][nl], g.b4a = params + L.off_b[1][nl];
+    g.logstd = params + L.off_logstd;
+    g.act = w.act, g.oldlogp = w.scal, g.adv = w.scal + M, g.ret_n = w.scal + 2 * M, g.val_n = w.scal + 3 * M;
+    g.adv_part = w.adv_part, g.n_adv_part = nbg;
+    g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
+    g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
+    g.part_w = w.head_w, g.part_s = w.head_s;
+    g.M = M, g.A = A, g.hp = *hp;
+    if (HL == 256) {
+      constexpr size_t lds = sizeof(float) * fwd_head_lds_floats<256>();
+      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_head_kernel<256>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)once;
+      fwd_head_kernel<256><<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
+    } else {
+      constexpr size_t lds = sizeof(float) * fwd_head_lds_floats<128>();
+      fwd_head_kernel<128><<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
+    }
+    CATPPO_CHECK_LAUNCH(ctx);
+    nbh = RB;
+  } else {
     // 2. hidden layers forward, both nets per launch
     forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s);
     CATPPO_CHECK_LAUNCH(ctx);
@@ -1233,12 +1597,16 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     if (l == nl - 1) {
       // head partials + diagnostics ride along with the reduction launch
       const int NS = head_scalars(A);
-      add_seg(w.head_w, grad + L.off_w[1][nl], (int64_t)A * HL, (int64_t)(A + 1) * HL, nbh, 0, 1.0f);
-      add_seg(w.head_w + (int64_t)A * HL, grad + L.off_w[0][nl], HL, (int64_t)(A + 1) * HL, nbh, 0, 1.0f);
+      // fused head: partial rows [0, nbh) come from the actor workgroups, [nbh, 2 nbh) from the critic's
+      const int64_t wrow = (int64_t)(A + 1) * HL;
+      const float* cw = w.head_w + (fused_head ? (int64_t)nbh * wrow : 0);
+      const float* cs = w.head_s + (fused_head ? (int64_t)nbh * NS : 0);
+      add_seg(w.head_w, grad + L.off_w[1][nl], (int64_t)A * HL, wrow, nbh, 0, 1.0f);
+      add_seg(cw + (int64_t)A * HL, grad + L.off_w[0][nl], HL, wrow, nbh, 0, 1.0f);
       add_seg(w.head_s, grad + L.off_b[1][nl], A, NS, nbh, 0, 1.0f);
-      add_seg(w.head_s + A, grad + L.off_b[0][nl], 1, NS, nbh, 0, 1.0f);
+      add_seg(cs + A, grad + L.off_b[0][nl], 1, NS, nbh, 0, 1.0f);
       add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
-      add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, nbh, 1, hp->inv_global_batch);
+      add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, fused_head ? 2 * nbh : nbh, 1, hp->inv_global_batch);
     }
     if (l > 0) {
       // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
