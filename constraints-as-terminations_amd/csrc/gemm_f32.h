@@ -80,14 +80,19 @@ __device__ __forceinline__ int xcd_tile_index(int wg, int nwg) {
 
 // One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
 // (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
-template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0>
+// WAVES_M: the four waves tile the workgroup's output as WAVES_M x (4 / WAVES_M); 2 x 2 by default, 1 x 4 for wide flat
+// tiles (64 x 256: every wave keeps the 64x64 shape of the 128x128 configuration).
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0, int WAVES_M = 2>
 __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, const int nwg, const int bz,
                                           float* __restrict__ smem) {
   constexpr int BK = BKT;                      // shadows gemm::BK inside the kernel
   constexpr int KC_STRIDE = BK + 4;            // floats, K-contig LDS row stride (80 B / 144 B: conflict-free b128)
   constexpr int KQ = BK / 4;                   // float4 per K-contig row of a slab
-  constexpr int TM = BM / 64, TN = BN / 64;  // 32x32 MFMA tiles per wave
-  constexpr int WM = BM / 2, WN = BN / 2;    // wave tile
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;    // wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;              // 32x32 MFMA tiles per wave
+  static_assert(WAVES_M == 1 || WAVES_M == 2, "wave layout");
+  static_assert(TM >= 1 && TN >= 1, "tile too small for the wave layout");
   constexpr int A_TILE = A_KC ? BM * KC_STRIDE : BK * BM;
   constexpr int B_TILE = B_KC ? BN * KC_STRIDE : BK * BN;
   constexpr int A_LD4 = BM * BK / 4 / 256;   // float4 loads per thread per slab
@@ -107,7 +112,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = WAVES_M == 2 ? wave >> 1 : 0, wn = WAVES_M == 2 ? wave & 1 : wave;
   const int l31 = lane & 31, h = lane >> 5;
 
   int k_begin = 0, k_end = p.Kc;

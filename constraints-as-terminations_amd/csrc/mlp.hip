@@ -805,6 +805,14 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
 //   B  dZ[64,HL]  = (G . Wh) * elu'(H)       written over H in LDS, then streamed out as whole rows
 // Partial rows [0, RB) belong to the actor workgroups, [RB, 2 RB) to the critic's (row layout of head_loss_kernel,
 // each kind writes only its own entries; the fold reads them with separate base pointers).
+// -DFWD_HEAD_TL (tools/fwd_head_timeline.py): thread 0 of every workgroup stamps the shader clock at the step boundaries
+#ifdef FWD_HEAD_TL
+__device__ unsigned long long* g_fhtl;    // [2 nets][1024 workgroups][8 stamps]
+#define FH_TL(i) do { if (threadIdx.x == 0 && g_fhtl) g_fhtl[(blockIdx.z * 1024 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FH_TL(i) do { } while (0)
+#endif
+
 template <int HL>
 constexpr size_t fwd_head_lds_floats() { return (size_t)64 * (HL + gemm::kLdsTilePad) + 64 * 16 + 64 * 16 + 64 * 8 + 4; }
 
@@ -856,6 +864,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
     }
   }
 
+  FH_TL(0);
   const float* Wh = net == 1 ? g.W4a : g.W4c;          // [KH][HL] head weights of this network
   const int KH = net == 1 ? A : 1;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -893,7 +902,8 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
   }
   const float rbc = g.b4c[0], rvv = g.vrms_var[0], rvm = g.vrms_mean[0];
 
-  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, 0, 1>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  FH_TL(1);
 
   // ---- A: head outputs.  MFMA step (blk, s) of lane-half h contracts k = 8 blk + 4 h + s - the same permutation on
   //         both operands (gemm_body's K-contiguous fragments)
@@ -915,13 +925,16 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
       c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, bw[kb].w, c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, bw[kb].w, c1, 0, 0, 0);
     }
-    for (int w = 0; w < 4; ++w) {                        // the four contraction quarters, added in fixed order
-      if (q == w && l31 < 16) {
+    // the four contraction quarters in fixed order, two rounds: sMu = q0 + q1, sG = q2 + q3 (sG is free until the row
+    // math writes it); the row math adds the two halves
+    for (int w = 0; w < 2; ++w) {
+      if ((q & 1) == w && l31 < 16) {
+        float* half = (q >> 1) ? sG : sMu;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-          float* d0 = sMu + row * 16 + l31;
-          float* d1 = sMu + (32 + row) * 16 + l31;
+          float* d0 = half + row * 16 + l31;
+          float* d1 = half + (32 + row) * 16 + l31;
           *d0 = (w == 0 ? 0.0f : *d0) + c0[r];
           *d1 = (w == 0 ? 0.0f : *d1) + c1[r];
         }
@@ -930,6 +943,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
     }
   }
 
+  FH_TL(2);
   const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
   // ---- row math: four threads per row
   {
@@ -949,7 +963,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
           const float sd = expf(rls[kk]);
           const float lsd = logf(sd);
           var[kk] = sd * sd;
-          const float mu = sMu[r * 16 + k] + rb[kk];
+          const float mu = (sMu[r * 16 + k] + sG[r * 16 + k]) + rb[kk];
           diff[kk] = ract[kk] - mu;
           lp += -(diff[kk] * diff[kk]) / (2.0f * var[kk]) - lsd - kHalfLog2Pi;
           en += kEntConst + lsd;
@@ -989,7 +1003,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
       const float vden = sqrtf(rvv + 1e-8f), vmean = rvm;
       const float vf_half = g.hp.vf_coef * 0.5f;
       const float R = rs0, Vo = rs1;
-      const float v = sMu[r * 16] + rbc;
+      const float v = (sMu[r * 16] + sG[r * 16]) + rbc;
       const float nv = (v - vmean) / vden;         // value_rms(newvalue, update=False)
       const float e1 = nv - R;
       const float vl1 = e1 * e1;
@@ -1013,6 +1027,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
   }
   __syncthreads();
 
+  FH_TL(3);
   // ---- C: head weight gradient of the tile, dWh[k][c] = sum_r G[r][k] H[r][c]; wave q owns TNC column tiles
   const int prow = net == 1 ? tile : RB + tile;
   {
@@ -1022,7 +1037,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
 #pragma unroll
       for (int r = 0; r < 16; ++r) cc[t][r] = 0.0f;
     const int col0 = q * (HL / 4);
-#pragma unroll 4
+#pragma unroll 8
     for (int s = 0; s < BM / 2; ++s) {
       const int r = 2 * s + h;
       const float a = l31 < 16 ? sG[r * 16 + l31] : 0.0f;
@@ -1040,6 +1055,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
       }
   }
   __syncthreads();                                       // every read of H is done: step B overwrites it
+  FH_TL(4);
 
   // ---- B: dZ = (G . Wh) * elu'(H), in place
   {
@@ -1069,6 +1085,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
       }
   }
   __syncthreads();
+  FH_TL(5);
   {
     const int cc = tid % NCH, rg = tid / NCH;
     float* dZ = net == 1 ? g.dZa : g.dZc;
@@ -1081,6 +1098,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
   // ---- scalars of the tile: bias / logstd gradients, diagnostics.  16 row groups of 4 rows, combined in fixed order
   //      through LDS (the H / dZ tile is free again once every row has been streamed out)
   __syncthreads();
+  FH_TL(6);
   {
     float* red = Hs;                                    // [16 groups][40]: 16 db, 16 dlogstd, 8 diag
     const int k = tid & 15, grp = tid >> 4;
@@ -1109,7 +1127,15 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
       ps[2 * A + 1 + tid - 32] = v;                        // diagnostics
     }
   }
+  FH_TL(7);
 }
+
+#ifdef FWD_HEAD_TL
+extern "C" int catppo_debug_fwd_head_tl(void* buf) {     // timeline builds only: not part of include/catppo.h
+  unsigned long long* pbuf = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fhtl), &pbuf, sizeof(pbuf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ------------------------------------------------------------------------------- segmented partial reduction
 // dst[e] (+)= scale * sum_{p<n_parts} src[p*stride + e]   in fixed order.  One launch handles every segment

@@ -387,6 +387,10 @@ def _minibatch_case(D, A, hidden, Bsz, M, seed):
     (48, 7, (64,), 1024, 512, (True, True)),                  # narrowest: one hidden layer of 64, 7 actions
     (33, 15, (64, 128, 64, 128), 1024, 300, (True, True)),    # deepest (4 hidden layers), widest action (15)
     (16, 1, (128, 64), 512, 65, (True, False)),               # one action dimension, minibatch of 65
+    # >= 8192 rows in fp32: last hidden layer + heads + loss run as ONE launch (fwd_head_kernel)
+    (48, 12, (256, 256, 256), 24576, 8229, (False, False)),   # 256-wide tile, ragged last 64-row tile, no adv-norm / v-clip
+    (45, 3, (256, 128), 16384, 8192, (True, True)),           # 128-wide tile, 3 actions
+    (48, 15, (128, 256), 16384, 8200, (True, False)),         # 15 actions (every head slot but one), two hidden layers
 ])
 @pytest.mark.parametrize("prec", [0, 2], ids=["fp32mfma", "bf16x3"])
 def test_ppo_minibatch_grad_vs_autograd_oracle(nat, D, A, hidden, Bsz, M, flags, prec):
