@@ -11,4 +11,15 @@ for WL in reference cfg3_shard cfg4 cfg5; do
   DB=$(find $dir -name '*.db' | head -1)
   [ -n "$DB" ] && python tools/rocpd_stats.py "$DB" > "$OUT/r2_bench_${WL}_kernel_stats.csv" && echo "$WL ok"
 done
-timeout 900 python -m pytest tests/test_gpu_r2_features.py -m gpu -q --timeout 600 -p no:cacheprovider 2>&1 | tail -3 | cut -c1-200
+# strong-scaling shares of cfg3 (16384 envs, 16384 minibatch GLOBAL): one rank's share at 1 / 2 / 4 / 8 ranks, no collectives
+: > "$OUT/r2_bench_cfg3_shares.jsonl"
+for W in 1 2 4 8; do
+  timeout 300 python bench.py --workload cfg3 --shard-of $W --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/r2_bench_cfg3_shares.jsonl"
+done
+python - "$OUT/r2_bench_cfg3_shares.jsonl" <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    if l.strip():
+        d = json.loads(l)
+        print("cfg3 share of", d["config"]["simulated_shard_of_world"], "ranks:", round(d["value"] / 1e6, 3), "M/s per rank, ms", round(d["ms_per_step"], 2))
+PY
