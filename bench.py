@@ -305,10 +305,13 @@ def main():
         M = min(trainer.mb, trainer.batch)
         if trainer.graph_update:                   # eager replay of the group on the data of the last iteration
             trainer._update_buffers()
+            # (env-sharded runs normalise advantages with the statistics of the GLOBAL minibatch: hand the kernel the
+            # first pair the last iteration computed)
+            adv_stats = trainer._adv_stats_all[0] if trainer.hp.adv_stats_external else None
             for _ in range(12):
                 timed_grad(trainer.agent.shape, trainer.hp, trainer.agent.flat, trainer._x_g, trainer._act_g,
                            trainer._scal_g, trainer._advp_g, M, trainer.agent.value_rms.running_mean,
-                           trainer.agent.value_rms.running_var, None, trainer.grad, trainer.diag)
+                           trainer.agent.value_rms.running_var, adv_stats, trainer.grad, trainer.diag)
             torch.cuda.synchronize()
             ev[:] = ev[2:]
         grad_us = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
