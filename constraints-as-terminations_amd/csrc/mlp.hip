@@ -816,8 +816,8 @@ __device__ unsigned long long* g_fhtl;    // [2 nets][1024 workgroups][8 stamps]
 template <int HL>
 constexpr size_t fwd_head_lds_floats() { return (size_t)64 * (HL + gemm::kLdsTilePad) + 64 * 16 + 64 * 16 + 64 * 8 + 4; }
 
-template <int HL>
-__global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const HeadArgs g) {
+template <int HL, int PREC = 0>      // PREC: operand precision of the hidden-layer GEMM (gemm_body); the head products stay fp32
+__global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const HeadArgs g) {   // two workgroups per CU
   using gemm::f32x16;
   constexpr int BM = 64, LD = HL + gemm::kLdsTilePad;
   constexpr int KQ = HL / 4;            // contraction share of a wave in step A
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256) void fwd_head_kernel(const Params p, const Hea
   }
   const float rbc = g.b4c[0], rvv = g.vrms_var[0], rvm = g.vrms_mean[0];
 
-  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, 0, 1>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, PREC, 1>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
   FH_TL(1);
 
   // ---- A: head outputs.  MFMA step (blk, s) of lane-half h contracts k = 8 blk + 4 h + s - the same permutation on
@@ -1465,13 +1465,13 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const int head_cap = 2 * head_lds > 160 * 1024 ? kHeadMaxBlocks / 2 : kHeadMaxBlocks;
   if (nbh > head_cap) nbh = head_cap;
 
-  // Large fp32 minibatches: the last hidden layer, the heads, the loss and the backward through the heads are ONE
+  // Large minibatches: the last hidden layer, the heads, the loss and the backward through the heads are ONE
   // launch (fwd_head_kernel).  Needs the full last-layer width in one tile (128 or 256 columns), a 16-aligned
   // contraction, and enough 64-row tiles to fill the chip (otherwise the 64x64-tile GEMM + head_loss pair has more
   // workgroups).  CATPPO_FUSED_HEAD=0 keeps the two launches.
   static const int fused_head_env = env_int("CATPPO_FUSED_HEAD", 1);
   const int RB = (int)cdiv64(M, 64);
-  const bool fused_head = fused_head_env && shape->mfma_bf16 == 0 && (HL == 128 || HL == 256) && nl >= 2 &&
+  const bool fused_head = fused_head_env && (HL == 128 || HL == 256) && nl >= 2 &&
                           L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= 256 && A <= 15;
   if (fused_head) {
     forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
@@ -1497,15 +1497,27 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
     g.part_w = w.head_w, g.part_s = w.head_s;
     g.M = M, g.A = A, g.hp = *hp;
+    auto launch_fh = [&](auto hl, auto prec) {
+      constexpr int HLc = decltype(hl)::value, PR = decltype(prec)::value;
+      constexpr size_t lds = sizeof(float) * fwd_head_lds_floats<HLc>();
+      auto kern = fwd_head_kernel<HLc, PR>;
+      if (lds > 64 * 1024) {
+        static const hipError_t once =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)once;
+      }
+      kern<<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
+    };
+    using std::integral_constant;
+    const int pr = shape->mfma_bf16;
     if (HL == 256) {
-      constexpr size_t lds = sizeof(float) * fwd_head_lds_floats<256>();
-      static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_head_kernel<256>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)once;
-      fwd_head_kernel<256><<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
+      if (pr == 0) launch_fh(integral_constant<int, 256>{}, integral_constant<int, 0>{});
+      else if (pr == 1) launch_fh(integral_constant<int, 256>{}, integral_constant<int, 1>{});
+      else launch_fh(integral_constant<int, 256>{}, integral_constant<int, 2>{});
     } else {
-      constexpr size_t lds = sizeof(float) * fwd_head_lds_floats<128>();
-      fwd_head_kernel<128><<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
+      if (pr == 0) launch_fh(integral_constant<int, 128>{}, integral_constant<int, 0>{});
+      else if (pr == 1) launch_fh(integral_constant<int, 128>{}, integral_constant<int, 1>{});
+      else launch_fh(integral_constant<int, 128>{}, integral_constant<int, 2>{});
     }
     CATPPO_CHECK_LAUNCH(ctx);
     nbh = RB;
