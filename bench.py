@@ -360,7 +360,7 @@ def main():
             "phases_device_ms": phases,
             "iteration_tflops": it_flops / (1e9 * dt / a.steps) / 1e3,
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (grouped fp32-MFMA forward GEMM launches, the last one "
-                         "with heads + loss + head backward in its epilogue when >= 8192 fp32 rows, else a head+loss launch; "
+                         "with heads + loss + head backward in its epilogue from 4096 rows up, else a head+loss launch; "
                          "paired split-K dW + dX GEMM launches, partial fold) per " + str(M) + "-sample minibatch",
                          "achieved": ach * mfma_flops_factor, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach * mfma_flops_factor / peak, "algorithmic_tflops": ach,

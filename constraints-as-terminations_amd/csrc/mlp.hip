@@ -1470,9 +1470,10 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   // contraction, and enough 64-row tiles to fill the chip (otherwise the 64x64-tile GEMM + head_loss pair has more
   // workgroups).  CATPPO_FUSED_HEAD=0 keeps the two launches.
   static const int fused_head_env = env_int("CATPPO_FUSED_HEAD", 1);
+  static const int fused_head_min = env_int("CATPPO_FUSED_HEAD_MIN_WG", 128);    // workgroups of the fused launch (M >= 4096)
   const int RB = (int)cdiv64(M, 64);
   const bool fused_head = fused_head_env && (HL == 128 || HL == 256) && nl >= 2 &&
-                          L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= 256 && A <= 15;
+                          L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= fused_head_min && A <= 15;
   if (fused_head) {
     forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
     CATPPO_CHECK_LAUNCH(ctx);
