@@ -672,3 +672,57 @@ def test_epoch_gather_plus_packed_grad_equals_gathering_grad(nat):
         np.testing.assert_array_equal(g1.cpu().numpy(), g2.cpu().numpy())
         np.testing.assert_array_equal(d1.cpu().numpy(), d2.cpu().numpy())
         assert np.abs(g1.cpu().numpy()).max() > 0
+
+
+_FUSED_VS_SPLIT = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "constraints-as-terminations_amd"))
+import streams as S
+import test_gpu_kernels as T
+from cat_envs import native
+D, A, hidden, Bsz, M = {D}, {A}, {hidden}, {Bsz}, {M}
+nat = native.Native()
+shape = native.shape_of(D, A, hidden, mfma_bf16={prec})
+lay = native.layout_of(shape)
+w = S.agent_weights(5, D, A, hidden)
+c = T._minibatch_case(D, A, hidden, Bsz, M, 6)
+c["logp"] = (c["logp"] * 0.0 - 11.0 + np.random.RandomState(3).standard_normal(Bsz) * 0.3).astype(np.float32)
+params = T.flat_params(native, shape, lay, w)
+obs_p = np.zeros((Bsz, lay.obs_pad), np.float32); obs_p[:, :D] = c["obs"]
+grad = torch.zeros(lay.n_flat, device="cuda"); diag = torch.zeros(8, device="cuda")
+hp = native.PpoHparams(0.2, 0.001, 2.0, 1, 1, 1.0 / M, 0)
+nat.mlp_reserve(shape, M)
+nat.ppo_minibatch_grad(shape, hp, params, T.dev(obs_p), T.dev(c["act"]), T.dev(c["logp"]), T.dev(c["adv"]),
+                       T.dev(c["ret"]), T.dev(c["val"]), T.dev(c["inds"]), T.dev(np.array([c["vmean"]])),
+                       T.dev(np.array([c["vvar"]])), None, grad, diag)
+torch.cuda.synchronize()
+np.savez({out!r}, grad=grad.cpu().numpy(), diag=diag.cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("D,A,hidden,Bsz,M,prec", [
+    (48, 12, (256, 256, 256), 16384, 16384, 0),      # cfg2's minibatch
+    (45, 12, (512, 256, 128), 8192, 4133, 0),        # reference shapes, ragged, just above the fused threshold
+    (48, 12, (256, 256, 256), 8192, 8192, 1),        # bf16 operands (cfg5)
+])
+def test_fused_head_launch_equals_the_two_launch_path(tmp_path, D, A, hidden, Bsz, M, prec):
+    """fwd_head_kernel (last hidden layer + heads + loss + head backward in one launch) against the forward GEMM +
+    head_loss_kernel pair it replaces: same minibatch, two processes (CATPPO_FUSED_HEAD is read once per process).
+    Different summation orders in the heads only: agreement far inside the oracle tolerance of the tests above."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"fused{flag}.npz")
+        code = _FUSED_VS_SPLIT.format(root=root, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=prec, out=out)
+        env = dict(os.environ, CATPPO_FUSED_HEAD=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    g1, g0 = outs[0]["grad"], outs[1]["grad"]
+    scale = np.abs(g0).max()
+    assert np.abs(g1 - g0).max() <= 2e-5 * scale, (np.abs(g1 - g0).max(), scale)
+    np.testing.assert_allclose(outs[0]["diag"][:7], outs[1]["diag"][:7], rtol=2e-5, atol=1e-7)
