@@ -4,7 +4,9 @@
 // Hidden layers run on the fp32 MFMA GEMM of gemm_f32.h (critic + actor grouped in one launch,
 // bias+ELU / ELU' fused in the epilogue).  The A-wide / 1-wide output heads, the Gaussian
 // log-prob / entropy, the clipped PPO losses AND their analytic gradients w.r.t. the last
-// hidden activations are one wave-per-row VALU kernel (head_loss): no autograd graph, no
+// hidden activations are one wave-per-row VALU kernel (head_loss) - or, from 4096 rows up and a
+// last layer of 128 / 256 columns, the epilogue of the last forward GEMM itself (fwd_head_kernel:
+// the activated tile stays in LDS, the head products run on the MFMA): no autograd graph, no
 // (M,12) temporaries, no host sync.  Weight gradients are split-K over the batch with
 // deterministic two-stage reduction (no float atomics => run-to-run reproducible); a layer's
 // weight-gradient and data-gradient GEMMs share one launch (gemm_pair_kernel), the minibatch is
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
 //   -  row math   one thread per row: log-prob / ratio / clipped surrogate / d loss/d mu, or value loss / d loss/d v
 //                 (the arithmetic of head_loss_kernel, ppo.py:299-345) -> G[64,16]
 //   C  dWh[16,HL] = G^T . H                  contraction over the 64 rows; per-workgroup partial
-//   B  dZ[64,HL]  = (G . Wh) * elu'(H)       written over H in LDS, then streamed out as whole rows
+//   B  dZ[64,HL]  = (G . Wh) * elu'(H)       written over H in LDS, every wave then streams out its own 32 x HL/2 region
 // Partial rows [0, RB) belong to the actor workgroups, [RB, 2 RB) to the critic's (row layout of head_loss_kernel,
 // each kind writes only its own entries; the fold reads them with separate base pointers).
 // -DFWD_HEAD_TL (tools/fwd_head_timeline.py): thread 0 of every workgroup stamps the shader clock at the step boundaries
@@ -823,8 +825,6 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   constexpr int KQ = HL / 4;            // contraction share of a wave in step A
   constexpr int TNB = HL / 64;          // 32-column tiles per wave in step B (waves 2 x 2)
   constexpr int TNC = HL / 128;         // 32-column tiles per wave in step C (waves 1 x 4)
-  constexpr int NCH = HL / 4;           // float4 chunks per row (copy-out)
-  constexpr int RG = 256 / NCH;         // row groups (copy-out)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                     // [64][LD]   activated tile, later dZ
   float* sG = Hs + BM * LD;             // [64][16]   d loss / d head output k of row r (zero beyond the real outputs)
@@ -1084,15 +1084,23 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
         *hp = cb[tn][r] * (hv > 0.0f ? 1.0f : hv + 1.0f);      // elu'(z) = 1 (z>0) | elu(z) + 1
       }
   }
-  __syncthreads();
+  // every wave streams out its own 32 x HL/2 region of dZ (LDS operations of a wave execute in order: no workgroup
+  // barrier between its in-place writes and these reads)
+  __builtin_amdgcn_wave_barrier();
   FH_TL(5);
   {
-    const int cc = tid % NCH, rg = tid / NCH;
+    constexpr int C4 = HL / 8;                 // float4 chunks per region row
+    constexpr int RPI = 64 / C4;               // region rows per store instruction
+    const int c4 = lane % C4, r_in = lane / C4;
     float* dZ = net == 1 ? g.dZa : g.dZc;
-    for (int r = rg; r < rows; r += RG) {
-      const float4 v = *reinterpret_cast<const float4*>(Hs + r * LD + 4 * cc);
-      const float o[4] = {v.x, v.y, v.z, v.w};
-      store_vec_wt<4>(dZ + (i0 + r) * HL + 4 * cc, o);
+#pragma unroll 4
+    for (int rb = 0; rb < 32; rb += RPI) {
+      const int r = 32 * wm + rb + r_in;
+      if (r < rows) {
+        const float4 v = *reinterpret_cast<const float4*>(Hs + r * LD + wn * (HL / 2) + 4 * c4);
+        const float o[4] = {v.x, v.y, v.z, v.w};
+        store_vec_wt<4>(dZ + (i0 + r) * HL + wn * (HL / 2) + 4 * c4, o);
+      }
     }
   }
   // ---- scalars of the tile: bias / logstd gradients, diagnostics.  16 row groups of 4 rows, combined in fixed order
