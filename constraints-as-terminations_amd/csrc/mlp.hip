@@ -148,11 +148,8 @@ void launch_gemm_bk(const Params& p, hipStream_t s) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);
   constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC, BKT>();
   auto kern = gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, BKT>;
-  if (lds > 64 * 1024) {
-    static const hipError_t once =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)once;
-  }
+  if (lds > 64 * 1024)     // per call, not once per process: the attribute belongs to the current device's copy of the kernel
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   kern<<<grid, dim3(256), lds, s>>>(p);
 }
 
@@ -1510,11 +1507,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       constexpr int HLc = decltype(hl)::value, PR = decltype(prec)::value;
       constexpr size_t lds = sizeof(float) * fwd_head_lds_floats<HLc>();
       auto kern = fwd_head_kernel<HLc, PR>;
-      if (lds > 64 * 1024) {
-        static const hipError_t once =
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)once;
-      }
+      if (lds > 64 * 1024)   // per call: the attribute belongs to the current device's copy of the kernel
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       kern<<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
     };
     using std::integral_constant;
