@@ -248,7 +248,11 @@ def main():
             overrides[k] = v
     w = WORKLOADS[a.workload]
     shard_world = a.shard_of if (a.shard_of > 0 and world == 1) else world
-    env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision, shard_world, rank, overrides)
+    # stdout carries ONE line (the JSON record): what building the env prints (the reference's "[INFO] Constraint
+    # Manager" table) goes to stderr
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision, shard_world, rank, overrides)
     nat = trainer.nat
     from cat_envs import parallel
 
