@@ -17,6 +17,15 @@ sys.path.insert(0, os.path.join(ROOT, "constraints-as-terminations_amd"))
 from cat_envs import native  # noqa: E402
 
 
+def peak_frac(algorithmic_tflops, prec):
+    """roofline fraction against the peak of the matrix instruction the mode executes: fp32 MFMA 157.3 TFLOP/s; bf16 MFMA
+    2500 TFLOP/s dense, with the split-bf16 mode executing three MFMAs per algorithmic product (never an fp32 fraction)"""
+    if prec == 0:
+        return {"frac_157TF_fp32_mfma": algorithmic_tflops / 157.3}
+    factor = 3.0 if prec == 2 else 1.0
+    return {"frac_2500TF_bf16_mfma": algorithmic_tflops * factor / 2500.0, "executed_over_algorithmic_flops": factor}
+
+
 def timeit(fn, reps, warmup=5):
     for _ in range(warmup):
         fn()
@@ -121,7 +130,7 @@ def main():
             us = timeit(lambda: nat.policy_act(shape, params, x, N, eps, act, lp, val), a.reps)
             fl = 2 * macs_true * N
             out.append(dict(kernel="policy_act" + tag, arch=list(hidden), D=D, N=N, us=us, TFLOPs=fl / us / 1e6,
-                            frac_157TF=fl / us / 1e6 / 157.3))
+                            **peak_frac(fl / us / 1e6, bf16)))
         B, M = 98304, 16384
         obs, acts = torch.randn(B, lay.obs_pad, device=dev), torch.randn(B, A, device=dev)
         logp, adv, ret, val = (torch.randn(B, device=dev) for _ in range(4))
@@ -134,7 +143,7 @@ def main():
                                                    None, grad, diag), max(a.reps // 2, 5))
         fl = 6 * macs_true * M
         out.append(dict(kernel="ppo_minibatch_grad" + tag, arch=list(hidden), D=D, M=M, us=us, TFLOPs=fl / us / 1e6,
-                        frac_157TF=fl / us / 1e6 / 157.3))
+                        **peak_frac(fl / us / 1e6, bf16)))
         m1, m2 = torch.zeros(lay.n_flat, device=dev), torch.zeros(lay.n_flat, device=dev)
         us = timeit(lambda: nat.clip_adam(params, grad, m1, m2, lay.n_flat, 1.0, 3e-4, 0.9, 0.999, 1e-5, 3), a.reps)
         out.append(dict(kernel="clip_adam(2 launches)", n=int(lay.n_flat), us=us, GBps=lay.n_flat * 28 / us / 1e3))
