@@ -152,9 +152,13 @@ def cpu_baseline(workload, trainer, env, agent_cfg, budget_s=15.0):
     dt = time.perf_counter() - t0
     tm = orc.timers
     steps = trainer.N * w["num_steps"] * n
-    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    # "cores" = the torch threads this baseline actually used (the contract's meaning); "host_cores" = what the box has
+    return {"value": steps / dt, "unit": "env-steps/s", "cores": cores, "threads": cores,
+            "host_cores": os.cpu_count(), "thread_choice": "best of {8,16,32,64,128} torch threads on a 16384-row MLP "
+                                                           "forward/backward probe (one thread per core is slower on "
+                                                           "this host)", "kind": "port",
             "sample": f"{n} full iterations of {trainer.N}x{w['num_steps']} (5 epochs, minibatches of "
-                      f"{min(trainer.mb, trainer.batch)}) after 1 warm-up iteration, {dt:.1f} s wall",
+                      f"{trainer.M}) after 1 warm-up iteration, {dt:.1f} s wall",
             "phase_ms_per_iteration": {"rollout_fwd_and_env": 1e3 * tm["rollout"] / n, "cat_env_step": 1e3 * tm["env"] / n,
                                        "gae": 1e3 * tm["gae"] / n, "update": 1e3 * tm["update"] / n}}
 
@@ -173,6 +177,40 @@ def pmc_traffic(workload, tag):
         return None, None, (f"profiles/{os.path.basename(path)} was measured on kernel sources {d.get('csrc_hash')}, the "
                             f"tree is {csrc_hash()}: re-run tools/profile_bench.sh")
     return d.get("hbm_bytes_per_launch"), os.path.basename(path), None
+
+
+GROUP_KERNELS = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel")
+
+
+def profiled_group_us(workload, tag):
+    """average duration of the dominant kernel group per minibatch from the COMMITTED rocprofv3 kernel trace of the same
+    command (profiles/<tag>_bench_<workload>_kernel_stats.csv): sum over the group's kernels of total time / number of
+    minibatches (one fold launch per minibatch), the rollout-only GEMM shapes excluded like tools/pmc_group_traffic.py
+    does.  Lets the bench line and profiles/ be diffed mechanically (should agree with avg_launch_us within a few %)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"{tag}_bench_{workload}_kernel_stats.csv")
+    try:
+        rows = list(csv.DictReader(open(path)))
+    except OSError:
+        return None, None
+    try:
+        n_mb = next(int(r["calls"]) for r in rows if "seg_reduce" in r["kernel"] or "fold_" in r["kernel"])
+    except StopIteration:
+        return None, os.path.basename(path)
+    def blocks(r):
+        x, y, z = (int(v) for v in r["blocks"].split("x"))
+        return x * y * z
+    us = 0.0
+    for r in rows:
+        if not any(k in r["kernel"] for k in GROUP_KERNELS + ("fold_",)):
+            continue
+        if "<64, 64, true, true, 0, 64" in r["kernel"] or "policy_fwd" in r["kernel"]:
+            continue                                   # rollout-only launches (<= 4096 rows)
+        if "<64, 64, true, true, 0" in r["kernel"]:    # first-layer forward: the rollout uses the same kernel on fewer rows
+            if blocks(r) < max(blocks(q) for q in rows if q["kernel"] == r["kernel"]):
+                continue
+        us += float(r["total_us"])
+    return us / n_mb, os.path.basename(path)
 
 
 def gae_roofline(nat, T, N, reps=50, mode=None):
@@ -213,7 +251,7 @@ def main():
                          "the bf16 peak).  bf16 = operands rounded to bf16 (BASELINE config 5): NOT a parity mode")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="PPO cfg override, e.g. --set graph_update=True --set rng=torch --set fused_rollout=False")
-    ap.add_argument("--profile-tag", default="r2", help="prefix of the PMC summaries under profiles/")
+    ap.add_argument("--profile-tag", default="r3", help="prefix of the PMC / kernel-trace summaries under profiles/")
     ap.add_argument("--shard-of", type=int, default=0, metavar="W",
                     help="single process, no collectives: run ONE rank's share of a strong-scaling workload as if the "
                          "world had W ranks (compute side of the scaling curve on a one-GPU box)")
@@ -306,7 +344,7 @@ def main():
     dt_nolog = time.perf_counter() - t1
 
     if rank == 0:
-        M = min(trainer.mb, trainer.batch)
+        M = trainer.M
         if trainer.graph_update:                   # eager replay of the group on the data of the last iteration
             trainer._update_buffers()
             # (env-sharded runs normalise advantages with the statistics of the GLOBAL minibatch: hand the kernel the
@@ -331,7 +369,8 @@ def main():
             pmc_traffic(a.workload, a.profile_tag)
         if traffic_note and not bf16:
             print(f"[bench] roofline.traffic = null: {traffic_note}", file=sys.stderr)
-        n_mb_steps = int(agent_cfg.updates_epochs) * ((trainer.batch + M - 1) // M)
+        prof_us, prof_src = (None, None) if bf16 else profiled_group_us(a.workload, a.profile_tag)
+        n_mb_steps = int(agent_cfg.updates_epochs) * trainer.n_mb
         it_flops = (w["num_steps"] * trainer.N * 2 * macs) + n_mb_steps * flops_per_launch     # rollout fwd + update
         from cat_envs import native
         out = {
@@ -370,6 +409,7 @@ def main():
                          "frac": ach * mfma_flops_factor / peak, "algorithmic_tflops": ach,
                          "executed_over_algorithmic_flops": mfma_flops_factor,
                          "traffic": traffic, "avg_launch_us": grad_us, "launches_timed": len(ev),
+                         "dominant_kernel_us_profiled": prof_us, "profiled_source": prof_src,
                          "timed": "eager replay after the timed region (update phase runs from a hipGraph)"
                                   if trainer.graph_update else "HIP events inside the timed region",
                          "flops_per_launch": flops_per_launch,

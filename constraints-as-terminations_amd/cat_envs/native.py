@@ -167,6 +167,9 @@ _SIGNATURES = {
     "catppo_comm_destroy": (C.c_int, [_vp]),
     "catppo_allreduce": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "catppo_broadcast": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
+    # ---- ABI 0.3
+    "catppo_graph_abort": (C.c_int, [_vp, _vp]),
+    "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -376,6 +379,13 @@ class Native:
         _chk(moments, torch.float64, "moments")
         self._ok(self.lib.catppo_adv_moments(self.h, _p(advantages), _p(inds), inds.numel(), int(minibatch),
                                              _p(moments), self._stream()))
+
+    def adv_moments_parts(self, adv_part_g, parts_per_mb, total, minibatch, moments):
+        """per-minibatch {sum, sum of squares, rows} from the chunk sums of the epoch gather (fp64)"""
+        _chk(adv_part_g, torch.float64, "adv_part_g")
+        _chk(moments, torch.float64, "moments")
+        self._ok(self.lib.catppo_adv_moments_parts(self.h, _p(adv_part_g), int(parts_per_mb), int(total),
+                                                   int(minibatch), _p(moments), self._stream()))
 
     def adv_stats(self, moments, n_minibatches, stats):
         self._ok(self.lib.catppo_adv_stats(self.h, _p(moments), int(n_minibatches), _p(stats), self._stream()))
@@ -616,6 +626,10 @@ class Native:
         gid, nn = C.c_int(-1), C.c_int(0)
         self._ok(self.lib.catppo_graph_end(self.h, self._stream(), C.byref(gid), C.byref(nn)))
         return gid.value, nn.value
+
+    def graph_abort(self):
+        """drop an active capture without keeping its graph (error path)"""
+        self.lib.catppo_graph_abort(self.h, self._stream())
 
     def graph_launch(self, gid: int):
         self._ok(self.lib.catppo_graph_launch(self.h, int(gid), self._stream()))

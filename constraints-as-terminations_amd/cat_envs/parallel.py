@@ -38,31 +38,38 @@ def init_native_comm(nat, group=None) -> bool:
         return True
     if not active(group) or os.environ.get("CATPPO_NATIVE_COMM", "1") == "0":
         return False
-    # Every rank must end up on the same transport: a rank that could not join (librccl not loadable, communicator
-    # set-up refused) votes no, and then ALL ranks keep torch.distributed (RCCL through PyTorch) - said on stderr
-    # and in native_comm_error(), never silently.
+    # Every rank must end up on the same transport, and nobody may enter the (blocking) communicator set-up unless
+    # everybody can: ncclCommInitRank waits for all ranks, so a rank that failed BEFORE it (librccl not loadable, a
+    # communicator already present) would leave the healthy ones stuck inside RCCL.  Hence two votes over the
+    # launcher's process group: (1) preconditions + the unique id, (2) the outcome of the set-up itself.  A "no" in
+    # either keeps ALL ranks on torch.distributed - said on stderr and in native_comm_error(), never silently.
     global _native_error
-    err = None
+    r, w = rank(group), world_size(group)
+    pre_err, uid = None, None
     try:
-        box = [nat.comm_unique_id() if rank(group) == 0 else None]
-    except RuntimeError as e:      # rank 0 could not even make an id: the others must not wait inside RCCL
-        box, err = [None], str(e)
-    dist.broadcast_object_list(box, src=0, group=group)
-    if box[0] is None:
-        err = err or "rank 0 could not create an RCCL unique id"
-    else:
+        if nat.comm_world:
+            pre_err = "a communicator already exists on this context"
+        else:
+            uid = nat.comm_unique_id()          # dlopens librccl on every rank; only rank 0's id is used
+    except (RuntimeError, OSError) as e:
+        pre_err = str(e)
+    pre = [None] * w
+    dist.all_gather_object(pre, (pre_err, uid if r == 0 else None), group=group)
+    failed = [(i, v[0]) for i, v in enumerate(pre) if v[0] is not None]
+    err = None
+    if not failed:
         try:
-            nat.comm_init(rank(group), world_size(group), box[0])
+            nat.comm_init(r, w, pre[0][1])
         except RuntimeError as e:
             err = str(e)
-    votes = [None] * world_size(group)
-    dist.all_gather_object(votes, err, group=group)
-    failed = [(r, v) for r, v in enumerate(votes) if v is not None]
-    if failed:
-        if err is None:
+        votes = [None] * w
+        dist.all_gather_object(votes, err, group=group)
+        failed = [(i, v) for i, v in enumerate(votes) if v is not None]
+        if failed and err is None:
             nat.comm_destroy()
-        _native_error = "; ".join(f"rank {r}: {v}" for r, v in failed)
-        if rank(group) == 0:
+    if failed:
+        _native_error = "; ".join(f"rank {i}: {v}" for i, v in failed)
+        if r == 0:
             import sys
             print(f"[catppo] native RCCL communicator unavailable, collectives stay on torch.distributed: "
                   f"{_native_error}", file=sys.stderr)
@@ -115,31 +122,79 @@ def shard_slice(n_total: int, r: int, w: int) -> slice:
     return slice(start, start + base + (1 if r < rem else 0))
 
 
-def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
-    if active(group):
-        if _use_native(t, group):
-            _native.allreduce(t, 0)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+def _host_staged(t: torch.Tensor, group) -> bool:
+    """device tensor on a process group whose backend has no device transport here (gloo: the CPU tests' backend,
+    and the way two ranks share ONE GPU in the 2-rank trainer test - RCCL refuses two ranks on one device): the
+    operand takes a round trip through host memory.  Correct, deterministic and slow; never the production transport."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _collective(t: torch.Tensor, group, native_call, torch_call):
+    if not active(group):
+        return t
+    if _use_native(t, group):
+        native_call(t)
+    elif _host_staged(t, group):
+        h = t.detach().cpu()
+        torch_call(h)
+        t.copy_(h)
+    else:
+        torch_call(t)
     return t
+
+
+def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
+    return _collective(t, group, lambda x: _native.allreduce(x, 0),
+                       lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group))
 
 
 def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
-    if active(group):
-        if _use_native(t, group):
-            _native.allreduce(t, 1)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return t
+    return _collective(t, group, lambda x: _native.allreduce(x, 1),
+                       lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group))
 
 
 def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
-    if active(group):
-        if _use_native(t, group):
-            _native.broadcast(t, src)
-        else:
-            dist.broadcast(t, src=src, group=group)
-    return t
+    return _collective(t, group, lambda x: _native.broadcast(x, src),
+                       lambda x: dist.broadcast(x, src=src, group=group))
+
+
+def gather_counts(n_local: int, device=None, group=None) -> list:
+    """[n of rank 0, n of rank 1, ...] as Python ints (one small SUM all-reduce; world of one: [n_local])"""
+    w, r = world_size(group), rank(group)
+    if not active(group):
+        return [int(n_local)]
+    v = torch.zeros(w, dtype=torch.float64, device=device)
+    v[r] = float(n_local)
+    allreduce_sum_(v, group)
+    return [int(round(x)) for x in v.cpu().tolist()]
+
+
+def minibatch_plan(batch_rows, minibatch: int):
+    """Minibatch schedule of an env-sharded update that every rank can derive from the same inputs.
+
+    ``batch_rows`` = rows (T x N_r) of every rank, ``minibatch`` = nominal per-rank minibatch size.  Shards may differ
+    (ragged env counts), so ``ceil(B_r / minibatch)`` can differ by one between ranks - and a rank that issues one
+    more gradient all-reduce than its peers hangs the job.  When the per-rank counts agree the configured size is kept
+    (a single process gets the reference's schedule); otherwise the plan fixes ONE minibatch count for all ranks (the
+    smallest per-rank count), gives rank r minibatches of ``M_r = ceil(B_r / n_mb)`` rows (the last one may be
+    shorter) and returns the TRUE number of rows of every global minibatch k (sum over ranks) for the 1/M_global loss
+    scaling.  Returns (n_mb, [M_r], [[rows of minibatch k on rank r]], [global rows of minibatch k])."""
+    rows = [int(b) for b in batch_rows]
+    if min(rows) < 1 or minibatch < 1:
+        raise ValueError(f"minibatch_plan: every rank needs at least one row (rows per rank {rows}, minibatch {minibatch})")
+    nominal = [min(minibatch, b) for b in rows]
+    counts = [(b + m - 1) // m for b, m in zip(rows, nominal)]
+    n_mb = min(counts)
+    if all(c == n_mb for c in counts):
+        m_r = nominal                      # every rank agrees: the configured schedule (single process: the reference's)
+    else:
+        m_r = [(b + n_mb - 1) // n_mb for b in rows]
+    per_rank = [[max(0, min(m, b - k * m)) for k in range(n_mb)] for b, m in zip(rows, m_r)]
+    if any(x == 0 for pr in per_rank for x in pr):
+        raise ValueError(f"minibatch_plan: shards {rows} cannot be cut into {n_mb} non-empty minibatches each; "
+                         "use env counts per rank that differ by at most one, or a smaller minibatch_size")
+    glob = [sum(pr[k] for pr in per_rank) for k in range(n_mb)]
+    return n_mb, m_r, per_rank, glob
 
 
 def global_moment_sums(sums_and_count: torch.Tensor, group=None) -> torch.Tensor:

@@ -331,11 +331,17 @@ class CaTEnv:
         rc = lib.catppo_rollout_pre(h, self._rstep_ref, stream)
         if rc:
             nat._ok(rc)
-        group = cm.dist_group
-        if group is not None and self._parallel.active(group):
-            colmax, sums = self._xchg_views
-            self._parallel.allreduce_max_(colmax, group)      # CaT column maxima: exact, masks stay bit-exact
-            self._parallel.allreduce_sum_(sums, group)        # observation moments (fp64)
+        # env-sharded runs: the two halves of the exchange buffer are reduced independently.  The CaT column maxima
+        # only in exact mode (cm.dist_group, set by the trainer under dist_exact); the observation moment sums
+        # whenever the consumer's normaliser is global (sink.obs_group) - its divisor obs_rows_total is then the
+        # global env count, so the sums MUST be global too (with dist_exact=False they used to stay local while the
+        # divisor was global: the running mean shrank by 1/world per update).
+        par = self._parallel
+        group, obs_group = cm.dist_group, getattr(sink, "obs_group", None)
+        if group is not None and par.active(group):
+            par.allreduce_max_(self._xchg_views[0], group)    # exact (max is order independent): masks stay bit-exact
+        if obs_group is not None and par.active(obs_group):
+            par.allreduce_sum_(self._xchg_views[1], obs_group)   # fp64 [sum x | sum x^2]
         rc = lib.catppo_rollout_post(h, self._rstep_ref, stream)
         if rc:
             nat._ok(rc)

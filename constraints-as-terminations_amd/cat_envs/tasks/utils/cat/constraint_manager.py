@@ -322,22 +322,23 @@ class ConstraintManager(ManagerBase):
         self._desc_key = self._params_key()
         return table
 
+    @staticmethod
+    def _term_key(cfg):
+        """snapshot of everything ONE descriptor row is built from: the term function and its parameters (scalars by
+        value, SceneEntityCfg by its resolved ids); ``max_p`` is not part of it (it travels with every launch)"""
+        row = [id(cfg.func)]
+        for k, v in cfg.params.items():
+            if isinstance(v, (int, float, str, bool)) or v is None:
+                row.append((k, v))
+            else:
+                ids = (getattr(v, "joint_ids", None), getattr(v, "body_ids", None))
+                row.append((k, id(v), tuple(str(i) for i in ids)))
+        return tuple(row)
+
     def _params_key(self):
-        """cheap snapshot of everything a descriptor row is built from: the term functions and their parameters
-        (scalars by value, SceneEntityCfg by its resolved ids).  In-place edits of ``term_cfg.params`` - with or
-        without a ``set_term_cfg`` call - change the key and rebuild the table; ``max_p`` is not part of it (it
-        travels with every launch)."""
-        key = []
-        for cfg in self._term_cfgs:
-            row = [id(cfg.func)]
-            for k, v in cfg.params.items():
-                if isinstance(v, (int, float, str, bool)) or v is None:
-                    row.append((k, v))
-                else:
-                    ids = (getattr(v, "joint_ids", None), getattr(v, "body_ids", None))
-                    row.append((k, id(v), tuple(str(i) for i in ids)))
-            key.append(tuple(row))
-        return tuple(key)
+        """per-term snapshots of the whole table.  In-place edits of ``term_cfg.params`` - with or without a
+        ``set_term_cfg`` call - change the key and rebuild the table."""
+        return tuple(self._term_key(cfg) for cfg in self._term_cfgs)
 
     def compute(self, reward: torch.Tensor | None = None, reset_mask: torch.Tensor | None = None,
                 dones: torch.Tensor | None = None) -> torch.Tensor:
@@ -456,9 +457,14 @@ class ConstraintManager(ManagerBase):
             raise ValueError(f"Constraint term '{term_name}' not found.")
         old = self._term_cfgs[i]
         self._term_cfgs[i] = cfg
-        # the curriculum rewrites max_p through here at every reset with the SAME cfg object (max_p travels with
-        # every launch); a different object / function / params dict makes _describe_terms() re-check its snapshot
-        if cfg is not old:
+        # The reference reads ``term_cfg.params`` on every compute() (constraint_manager.py:213-221), so an edit that
+        # arrives here - a new cfg object OR the same object after an in-place ``params[...] = x`` - must reach the very
+        # next step: compare this term's parameter snapshot with the one the cached descriptor row was built from (one
+        # small tuple; the curriculum calls this for every term at every reset with unchanged params: max_p is not in
+        # the snapshot, it travels with every launch).  The 64-step sweep in _describe_terms() only remains for edits
+        # that never go through set_term_cfg.
+        key = self._desc_key
+        if cfg is not old or key is None or self._term_key(cfg) != key[i]:
             self._desc_dirty = True
             if cfg.func is not old.func:
                 self._desc_cache = None

@@ -295,6 +295,10 @@ class RolloutSink:
         self._p_obs, self._obs_row = t.obs.data_ptr(), t.N * t.Dp * 4
         self._dtype = native.F16 if t.plane_dtype == torch.float16 else native.F32
         self._struct = None
+        #: process group over which the env all-reduces the observation moment sums of the fused step (None: this
+        #: rank's rows are the whole batch).  Independent of ``dist_exact``: like the unfused path, whose
+        #: ``obs_rms.dist_group`` is always the world, the normaliser sees the GLOBAL batch in every sharded run.
+        self.obs_group = rms.dist_group if (rms.dist_group is not None and parallel.active(rms.dist_group)) else None
 
     def fill(self, st):
         k = self.step
@@ -302,7 +306,8 @@ class RolloutSink:
             self._struct = st
             st.plane_dtype = self._dtype
             st.obs_mean, st.obs_var, st.obs_count, st.obs_eps = self._rms
-            st.obs_rows_total = self.t.n_envs_global
+            # the divisor of the moment sums must match what was summed: all ranks' rows only if they are exchanged
+            st.obs_rows_total = self.t.n_envs_global if self.obs_group is not None else float(self.t.N)
             st.obs_out_ld = self.t.Dp
         row = self._row
         st.rewards_t = self._p_rew + k * row
@@ -346,6 +351,7 @@ class PPOTrainer:
             raise ValueError(f"lr_schedule must be None, 'linear', 'fixed' or 'adaptive', got {sched!r}")
         self.lr_schedule = sched
         self.n_envs_global = float(self.N)
+        rows_per_rank, me = [self.batch], 0
         if parallel.active():
             parallel.init_native_comm(self.nat)                 # RCCL under the C ABI (catppo_comm_init)
             parallel.broadcast_(a.flat, src=0)                  # replicas start identical (cf. skrl ppo.py:126-131)
@@ -353,9 +359,16 @@ class PPOTrainer:
             cm = getattr(envs.unwrapped, "constraint_manager", None)
             if cm is not None and getattr(c, "dist_exact", True):
                 cm.dist_group = torch.distributed.group.WORLD
-            cnt = torch.tensor([float(self.N)], dtype=torch.float64, device=self.device)
-            parallel.allreduce_sum_(cnt)
-            self.n_envs_global = float(cnt.item())              # shards may differ by one env
+            counts = parallel.gather_counts(self.N, self.device)      # shards may differ by one env
+            self.n_envs_global = float(sum(counts))
+            rows_per_rank, me = [self.T * n for n in counts], (self.rank if len(counts) > 1 else 0)
+            mbs = parallel.gather_counts(self.mb, self.device)
+            if len(set(mbs)) != 1:
+                raise ValueError(f"minibatch_size differs between ranks: {mbs}")
+        # ONE minibatch schedule for all ranks (ragged shards would otherwise disagree on the number of gradient
+        # all-reduces), with the true global row count of every minibatch for the 1/M_global loss scaling
+        self.n_mb, m_r, per_rank, self._mb_rows_global = parallel.minibatch_plan(rows_per_rank, self.mb)
+        self.M, self._mb_rows = m_r[me], per_rank[me]
         cm = getattr(envs.unwrapped, "constraint_manager", None)
         if cm is not None and hasattr(cm, "ensure_log_ring"):
             cm.ensure_log_ring(self.T + 2)      # the per-step episode logs are read after the rollout
@@ -387,8 +400,8 @@ class PPOTrainer:
         self.diag = z(8)
         self.adv_stats = z(2)
         self.hp = native.PpoHparams(float(c.clip_coef), float(c.ent_coef), float(c.vf_coef), int(bool(c.norm_adv)),
-                                    int(bool(c.clip_vloss)), 1.0 / (min(self.mb, self.batch) * self.world), 0)
-        self.nat.mlp_reserve(a.shape, max(min(self.mb, self.batch), N))
+                                    int(bool(c.clip_vloss)), 1.0 / self._mb_rows_global[0], 0)
+        self.nat.mlp_reserve(a.shape, max(self.M, N))
         self.iteration = 0
         self.global_step = 0
         # fused env step (two launches) when the env offers it
@@ -403,7 +416,7 @@ class PPOTrainer:
         if env_g is not None:
             g = env_g == "1"
         if g is None:
-            g = min(self.mb, self.batch) <= 4096
+            g = self.M <= 4096
         dist_on_torch = parallel.active() and not parallel.native_comm_active()
         # RCCL collectives inside a captured graph are exercised on a world of one here (a one-GPU box); with real
         # peers they stay opt-in (CATPPO_GRAPH_COMM=1) until measured on a multi-GPU node
@@ -523,8 +536,7 @@ class PPOTrainer:
     def _update_buffers(self):
         if not hasattr(self, "_x_g"):
             # packed epoch buffers: one gather launch per epoch, minibatch k = contiguous slice k
-            B, M = self.batch, min(self.mb, self.batch)
-            n_mb = (B + M - 1) // M
+            B, M, n_mb = self.batch, self.M, self.n_mb
             self._parts = (M + self.nat.GATHER_ROWS - 1) // self.nat.GATHER_ROWS
             self._x_g = torch.empty(B, self.Dp, device=self.device)
             self._act_g = torch.empty(B, self.A, device=self.device)
@@ -533,42 +545,37 @@ class PPOTrainer:
             E = int(self.cfg.updates_epochs)
             self._adv_mom = torch.zeros(E * n_mb, 3, dtype=torch.float64, device=self.device)
             self._adv_stats_all = torch.zeros(E * n_mb, 2, device=self.device)
-            self._perm_dev = torch.zeros(B, dtype=torch.int64, device=self.device)
 
     def _update_body(self, perms):
         """the launches of one update phase (E epochs x minibatches).  ``perms``: list of index tensors (injected /
         torch.randperm) or None = keyed on-device permutation.  Contains no host synchronisation, no allocation and
         only library calls (+ RCCL through the C ABI), so it can be captured into a hipGraph."""
         c, a, nat = self.cfg, self.agent, self.nat
-        B, M = self.batch, min(self.mb, self.batch)
+        B, M, n_mb = self.batch, self.M, self.n_mb
         b_obs = self.obs[:self.T].view(B, self.Dp)
         b_act = self.actions.view(B, self.A)
         b_logp, b_adv = self.logprobs.view(-1), self.advantages.view(-1)
         b_ret, b_val = self.returns_n.view(-1), self.values_n.view(-1)
         vmean, vvar = a.value_rms.running_mean, a.value_rms.running_var
         E = int(c.updates_epochs)
-        n_mb = (B + M - 1) // M
         exact_adv = parallel.active() and bool(c.norm_adv) and getattr(c, "dist_exact", True)
         self.hp.adv_stats_external = int(exact_adv)
         for epoch in range(E):
             rec = self.perm_rec[epoch] if self.perm_rec is not None else None
-            if exact_adv and perms is None and rec is None:
-                rec = self._perm_dev                              # the moments below need the permutation
             nat.ppo_gather_ex(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, B, M, self._x_g, self._act_g,
                               self._scal_g, self._advp_g, inds=None if perms is None else perms[epoch],
                               st=self.state, epoch=epoch, inds_out=rec if perms is None else None)
             if exact_adv:
                 # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318): the moments of every
-                # minibatch of the epoch in one launch, ONE all-reduce, one finishing launch
-                if b_adv.dtype != torch.float32:
-                    raise NotImplementedError("dist_exact advantage statistics with fp16 rollout planes")
+                # minibatch of the epoch from the chunk sums the gather just wrote (any plane precision, no index
+                # array), ONE all-reduce, one finishing launch
                 mom = self._adv_mom[epoch * n_mb:(epoch + 1) * n_mb]
-                nat.adv_moments(b_adv, perms[epoch] if perms is not None else rec, M, mom)
+                nat.adv_moments_parts(self._advp_g, self._parts, B, M, mom)
                 parallel.allreduce_sum_(mom)
                 nat.adv_stats(mom, n_mb, self._adv_stats_all[epoch * n_mb:(epoch + 1) * n_mb])
-            for k, start in enumerate(range(0, B, M)):
-                m = min(M, B - start)
-                self.hp.inv_global_batch = 1.0 / (m * self.world)
+            for k in range(n_mb):
+                start, m = k * M, self._mb_rows[k]
+                self.hp.inv_global_batch = 1.0 / self._mb_rows_global[k]     # mean over the GLOBAL minibatch
                 adv_stats = self._adv_stats_all[epoch * n_mb + k] if exact_adv else None
                 nat.ppo_minibatch_grad_packed(a.shape, self.hp, a.flat, self._x_g[start:], self._act_g[start:],
                                               self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
@@ -607,8 +614,13 @@ class PPOTrainer:
             self.nat.graph_begin()
             try:
                 self._graph_steps = self._update_body(None)
-            finally:
-                self._graph_id, self.graph_nodes = self.nat.graph_end()
+            except BaseException:
+                # a failure between begin and end leaves a PARTIAL capture: never instantiate or replay it, and let
+                # the original error surface (ending the capture may itself fail once the capture is invalidated)
+                self.nat.graph_abort()
+                self._graph_id = None
+                raise
+            self._graph_id, self.graph_nodes = self.nat.graph_end()
             self.nat.graph_launch(self._graph_id)
             self.adam_step += self._graph_steps
             return

@@ -75,26 +75,35 @@ extern "C" int catppo_reserve(catppo_ctx* ctx, uint64_t bytes) {
   (void)hipSetDevice(ctx->device);
   // the old block may still be referenced by enqueued kernels: drain before freeing
   (void)hipDeviceSynchronize();
+  // captured graphs hold pointers into the old block: drop them BEFORE it is freed (a graph that outlived its
+  // workspace - e.g. when the hipMalloc below fails - would replay through dangling pointers; without a graph
+  // catppo_graph_launch fails and the caller captures again)
+  for (auto& g : ctx->graphs)
+    if (g) {
+      (void)hipGraphExecDestroy(g);
+      g = nullptr;
+    }
   // release the old block BEFORE asking for the bigger one: the allocator can then extend / reuse its address range
   // instead of placing the new block wherever a hole of that size is left (a workspace that grew after other
   // allocations was measured 1.7x slower for the GEMMs that live in it - fragmented placement)
+  const uint64_t old_bytes = ctx->ws_bytes;
   if (ctx->ws) (void)hipFree(ctx->ws);
   ctx->ws = nullptr;
   ctx->ws_bytes = 0;
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
+    // keep the context usable at its previous size (the calls that fitted before still fit)
+    void* q = nullptr;
+    if (old_bytes && hipMalloc(&q, old_bytes) == hipSuccess) {
+      ctx->ws = q;
+      ctx->ws_bytes = old_bytes;
+    }
     (void)hipSetDevice(cur);
     return catppo_fail(ctx, CATPPO_E_HIP, "catppo_reserve: hipMalloc(%llu) failed: %s", (unsigned long long)bytes,
                        hipGetErrorString(e));
   }
-  // captured graphs hold pointers into the old block: drop them (catppo_graph_launch then fails and the caller
-  // captures again)
-  for (auto& g : ctx->graphs)
-    if (g) {
-      (void)hipGraphExecDestroy(g);
-      g = nullptr;
-    }
   ctx->ws = p;
   ctx->ws_bytes = bytes;
   (void)hipSetDevice(cur);
@@ -142,6 +151,17 @@ extern "C" int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, in
     return catppo_fail(ctx, CATPPO_E_HIP, "catppo_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
   ctx->graphs[slot] = ex;
   *graph_id = slot;
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_graph_abort(catppo_ctx* ctx, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  if (!ctx->capturing) return CATPPO_OK;
+  ctx->capturing = false;
+  hipGraph_t g = nullptr;
+  (void)hipStreamEndCapture(static_cast<hipStream_t>(stream), &g);   // may itself fail if the capture was invalidated
+  if (g) (void)hipGraphDestroy(g);
+  (void)hipGetLastError();
   return CATPPO_OK;
 }
 

@@ -129,6 +129,23 @@ __global__ __launch_bounds__(256) void adv_moments_kernel(const float* __restric
   }
 }
 
+// the same moments from the 64-row chunk sums the epoch gather wrote: one wave per minibatch, lane-strided partial
+// sums in fixed order, then a butterfly (order depends on the chunk count only => run-to-run reproducible)
+__global__ __launch_bounds__(64) void adv_moments_parts_kernel(const double* __restrict__ parts, int parts_per_mb,
+                                                               int64_t total, int64_t mb, double* __restrict__ out) {
+  const double* p = parts + 2 * (int64_t)blockIdx.x * parts_per_mb;
+  double a = 0.0, b = 0.0;
+  for (int c = threadIdx.x; c < parts_per_mb; c += 64) a += p[2 * c], b += p[2 * c + 1];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64), b += __shfl_xor(b, m, 64);
+  if (threadIdx.x == 0) {
+    const int64_t lo = (int64_t)blockIdx.x * mb, hi = lo + mb < total ? lo + mb : total;
+    out[3 * blockIdx.x] = a;
+    out[3 * blockIdx.x + 1] = b;
+    out[3 * blockIdx.x + 2] = (double)(hi - lo);
+  }
+}
+
 // moments (after the SUM all-reduce) -> {mean, unbiased std + 1e-8} per minibatch (ppo.py:316-318)
 __global__ void adv_stats_kernel(const double* __restrict__ mom, int n, float* __restrict__ stats) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,6 +166,18 @@ extern "C" int catppo_adv_moments(catppo_ctx* ctx, const float* advantages, cons
   const int64_t n_mb = cdiv64(total, minibatch);
   hipLaunchKernelGGL(adv_moments_kernel, dim3((unsigned)n_mb), dim3(256), 0, static_cast<hipStream_t>(stream), advantages,
                      inds, total, minibatch, moments);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_adv_moments_parts(catppo_ctx* ctx, const double* adv_part_g, int parts_per_mb, int64_t total,
+                                        int64_t minibatch, double* moments, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, adv_part_g && moments && parts_per_mb >= 1 && total >= 1 && minibatch >= 1);
+  CATPPO_CHECK_ARG(ctx, (int64_t)parts_per_mb * 64 >= minibatch);
+  const int64_t n_mb = cdiv64(total, minibatch);
+  hipLaunchKernelGGL(adv_moments_parts_kernel, dim3((unsigned)n_mb), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     adv_part_g, parts_per_mb, total, minibatch, moments);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

@@ -56,6 +56,7 @@ struct Params {
   int splits;            // EPI_PARTIAL: contraction split count (blockIdx.z / nets)
   int kc_per_split;      // multiple of BK
   int64_t c_split_stride;  // floats between consecutive split outputs
+  int xcd_legacy;        // 1: round-2 workgroup order (tiles permuted inside one (net, split) only) - A/B switch
 };
 
 // ELU(alpha=1).  exp through the hardware exp2 (v_exp_f32, ~1 ulp on the (0,1] range that matters
@@ -78,13 +79,28 @@ __device__ __forceinline__ int xcd_tile_index(int wg, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
 }
 
-// One workgroup's tile.  `wg_raw` / `nwg` = index and count of the workgroups of this problem in launch order
-// (blockIdx.x / gridDim.x of a plain launch), `bz` = net + nets * split.
+// (tile, bz) of a workgroup of a launch whose grid is `tiles` x `nz` problems-slices (bz = net + nets * split), given its
+// linear position `lin` in launch order.  The hardware deals workgroups to the XCDs round-robin over the WHOLE launch
+// (lin % 8), so the unit that must stay together on one L2 is not "the tiles of this z-slice" but "consecutive logical
+// indices": every XCD gets a contiguous range of (bz, tile) pairs, tile fastest.  Round 2 permuted the tile index
+// inside one z-slice only; with few tiles per slice (a 256x256 weight gradient: 4 tiles x 64 (net, split) slices) the
+// four tiles that read the SAME 512-row slabs of dZ and H then sat on four different XCDs and every slab was fetched
+// from HBM twice (rocprofv3 FETCH_SIZE of the paired launch: 203 MB for 134 MB of operands).
+struct TileId {
+  int tile, bz;
+};
+__device__ __forceinline__ TileId xcd_tile_of(int lin, int tiles, int nz, int legacy) {
+  if (legacy) return TileId{xcd_tile_index(lin % tiles, tiles), lin / tiles};
+  const int l = xcd_tile_index(lin, tiles * nz);
+  return TileId{l % tiles, l / tiles};
+}
+
+// One workgroup's tile.  `wg` = tile index inside the problem (j fastest), `bz` = net + nets * split; both come from
+// xcd_tile_of.
 // WAVES_M: the four waves tile the workgroup's output as WAVES_M x (4 / WAVES_M); 2 x 2 by default, 1 x 4 for wide flat
 // tiles (64 x 256: every wave keeps the 64x64 shape of the 128x128 configuration).
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0, int WAVES_M = 2>
-__device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, const int nwg, const int bz,
-                                          float* __restrict__ smem) {
+__device__ __forceinline__ void gemm_body(const Params& p, const int wg, const int bz, float* __restrict__ smem) {
   constexpr int BK = BKT;                      // shadows gemm::BK inside the kernel
   constexpr int KC_STRIDE = BK + 4;            // floats, K-contig LDS row stride (80 B / 144 B: conflict-free b128)
   constexpr int KQ = BK / 4;                   // float4 per K-contig row of a slab
@@ -106,7 +122,6 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
   const int split = bz / p.nets;
   const Operands op = p.op[net];   // by value: pointers live in SGPRs for the whole kernel
   const int tiles_j = (p.J + BN - 1) / BN;
-  const int wg = xcd_tile_index(wg_raw, nwg);     // j fastest within an XCD's range
   const int i0 = (wg / tiles_j) * BM;
   const int j0 = (wg % tiles_j) * BN;
   const int tid = threadIdx.x;
@@ -448,7 +463,8 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg_raw, con
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT = BK, int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT, PREC>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  const gemm::TileId t = xcd_tile_of(blockIdx.x + gridDim.x * blockIdx.z, gridDim.x, gridDim.z, p.xcd_legacy);
+  gemm_body<BM, BN, A_KC, B_KC, EPI, BKT, PREC>(p, t.tile, t.bz, smem);
 }
 
 // Two independent problems in ONE launch: the first n0 workgroups (in launch order) run problem 0, the rest
@@ -462,10 +478,12 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const Params p0, const P
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < n0) {
-    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0, BK, PREC>(p0, b % tiles0, tiles0, b / tiles0, smem);
+    const TileId t = xcd_tile_of(b, tiles0, n0 / tiles0, p0.xcd_legacy);
+    gemm_body<BM0, BN0, A_KC0, B_KC0, EPI0, BK, PREC>(p0, t.tile, t.bz, smem);
   } else {
-    const int c = b - n0;
-    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1, BK, PREC>(p1, c % tiles1, tiles1, c / tiles1, smem);
+    // the XCD of workgroup b is b % 8 = (c + n0) % 8: grouping by c % 8 is the same partition for any n0
+    const TileId t = xcd_tile_of(b - n0, tiles1, (gridDim.x - n0) / tiles1, p1.xcd_legacy);
+    gemm_body<BM1, BN1, A_KC1, B_KC1, EPI1, BK, PREC>(p1, t.tile, t.bz, smem);
   }
 }
 

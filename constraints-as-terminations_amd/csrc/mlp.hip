@@ -141,6 +141,11 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+// CATPPO_XCD_LEGACY=1: the round-2 workgroup -> tile order (A/B of the launch-wide XCD mapping, see gemm::xcd_tile_of)
+static int xcd_legacy() {
+  static const int v = env_int("CATPPO_XCD_LEGACY", 0);
+  return v;
+}
 
 // fp32 launch with a wider contraction slab (latency-bound small-M launches: fewer global round trips per tile)
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT>
@@ -266,6 +271,7 @@ void forward_hidden(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, cons
   if (n_layers < 0) n_layers = sh->n_hidden;
   for (int l = 0; l < n_layers; ++l) {
     Params p{};
+    p.xcd_legacy = xcd_legacy();
     p.nets = nets;
     p.splits = 1;
     p.I = (int)M;
@@ -899,7 +905,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   }
   const float rbc = g.b4c[0], rvv = g.vrms_var[0], rvm = g.vrms_mean[0];
 
-  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, PREC, 1>(p, blockIdx.x, gridDim.x, blockIdx.z, smem);
+  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, PREC, 1>(p, tile, blockIdx.z, smem);
   FH_TL(1);
 
   // ---- A: head outputs.  MFMA step (blk, s) of lane-half h contracts k = 8 blk + 4 h + s - the same permutation on
@@ -1483,6 +1489,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
     CATPPO_CHECK_LAUNCH(ctx);
     Params p{};
+    p.xcd_legacy = xcd_legacy();
     p.nets = 2, p.splits = 1;
     p.I = (int)M, p.J = HL, p.Kc = L.in_dim[nl - 1];
     p.lda = p.Kc, p.ldb = p.Kc, p.ldc = HL;
@@ -1590,6 +1597,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     }
     // weight gradient: dW[out,in] = dZ^T . Xin      (contraction over the M rows)
     Params pw{};
+    pw.xcd_legacy = xcd_legacy();
     pw.nets = 2;
     pw.I = out, pw.J = in, pw.Kc = (int)M;
     pw.lda = out, pw.ldb = in, pw.ldc = in;
@@ -1652,6 +1660,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     if (l > 0) {
       // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
       Params px{};
+      px.xcd_legacy = xcd_legacy();
       px.nets = 2;
       px.splits = 1;
       px.I = (int)M, px.J = in, px.Kc = out;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CATPPO_VERSION 200 /* 0.2.0 */
+#define CATPPO_VERSION 300 /* 0.3.0 */
 
 #define CATPPO_OK 0
 #define CATPPO_E_ARG (-1)     /* bad argument */
@@ -183,6 +183,11 @@ int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const float* done
 int catppo_adv_moments(catppo_ctx* ctx, const float* advantages, const int64_t* inds, int64_t total,
                        int64_t minibatch, double* moments, void* stream);
 int catppo_adv_stats(catppo_ctx* ctx, const double* moments, int n_minibatches, float* stats, void* stream);
+/* the same moments from the per-chunk partial sums catppo_ppo_gather[_ex] already wrote (`adv_part_g`:
+ * [n_mb][parts_per_mb][2] fp64, parts_per_mb = ceil(minibatch / 64)) - no index array, any advantage plane
+ * precision (the gather widened fp16 exactly).  moments[m] = {sum, sum of squares, rows of minibatch m}. */
+int catppo_adv_moments_parts(catppo_ctx* ctx, const double* adv_part_g, int parts_per_mb, int64_t total,
+                             int64_t minibatch, double* moments, void* stream);
 
 /* ---- GAE -------------------------------------------------------------------------------
  * time-major (T,N) buffers; float dones in [0,1]; separate time-out mask.
@@ -517,6 +522,9 @@ int catppo_graph_begin(catppo_ctx* ctx, void* stream);
 int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, int* n_nodes);
 int catppo_graph_launch(catppo_ctx* ctx, int graph_id, void* stream);
 int catppo_graph_destroy(catppo_ctx* ctx, int graph_id);
+/* end a capture WITHOUT keeping its graph (error path: something between begin and end failed, the partial graph must
+ * never be replayed).  No-op when no capture is active. */
+int catppo_graph_abort(catppo_ctx* ctx, void* stream);
 
 /* ---- collectives (RCCL over xGMI, one process per GPU) ---------------------------------------------------------
  * librccl is loaded at run time (dlopen) by the first of these calls; the library has no link-time dependency on it.

@@ -360,8 +360,11 @@ class PPOOracle:
         last_stats = None
         for epoch in range(c["updates_epochs"]):
             inds = torch.randperm(B) if perm_fn is None else perm_fn(epoch)
-            for start in range(0, B, M):
-                mb = inds[start:start + M]
+            # a list of index tensors = the minibatches themselves (env-sharded runs: global minibatch k is the
+            # union of the ranks' k-th local minibatches, whose sizes need not be a fixed stride of one permutation)
+            mbs = list(inds) if isinstance(inds, (list, tuple)) else [inds[s0:s0 + M] for s0 in range(0, B, M)]
+            n_mbs = len(mbs) if isinstance(inds, (list, tuple)) else None
+            for mb in mbs:
                 loss, st = ppo_minibatch_loss(self.agent, b_obs[mb], b_act[mb], b_logp[mb], b_adv[mb],
                                               b_returns[mb], b_values[mb], c)
                 for k in sums:
@@ -375,7 +378,7 @@ class PPOOracle:
         self.timers["rollout"] += t1 - t0
         self.timers["gae"] += t2 - t1
         self.timers["update"] += t3 - t2
-        n_upd = c["updates_epochs"] * B / M
+        n_upd = c["updates_epochs"] * (B / M if n_mbs is None else n_mbs)
         out = {f"mean_{k}": float(v) / n_upd for k, v in sums.items()}
         out["lr"] = self.opt.param_groups[0]["lr"]
         out["advantages"], out["returns"] = adv, returns

@@ -140,8 +140,10 @@ def _worker(rank, world, port, out_dir):
     # ---- 3d. the native communicator set-up is all-or-nothing: rank 1 cannot join -> BOTH ranks keep
     #          torch.distributed and know why; then rank 0 cannot even make an id -> same outcome, nobody hangs
     class _Nat:
+        comm_world = 0
+
         def __init__(self, fail_id=False, fail_init=False):
-            self.fail_id, self.fail_init, self.destroyed = fail_id, fail_init, False
+            self.fail_id, self.fail_init, self.destroyed, self.init_calls = fail_id, fail_init, False, 0
 
         def comm_unique_id(self):
             if self.fail_id:
@@ -150,6 +152,7 @@ def _worker(rank, world, port, out_dir):
 
         def comm_init(self, r, w, uid):
             assert len(uid) == 128 and w == world
+            self.init_calls += 1
             if self.fail_init:
                 raise RuntimeError("libcatppo error -6: ncclCommInitRank: unhandled system error")
 
@@ -163,6 +166,13 @@ def _worker(rank, world, port, out_dir):
     nat_b = _Nat(fail_id=(rank == 0))
     assert parallel.init_native_comm(nat_b) is False and "unique id" in parallel.native_comm_error() or \
         "librccl" in parallel.native_comm_error()
+    assert nat_b.init_calls == 0                   # nobody entered the (blocking) communicator set-up
+    # a rank that cannot load librccl at all (precondition vote): the healthy rank must NOT enter ncclCommInitRank,
+    # where it would wait for the missing peer forever
+    nat_c = _Nat(fail_id=(rank == 1))
+    assert parallel.init_native_comm(nat_c) is False and "rank 1" in parallel.native_comm_error()
+    assert nat_c.init_calls == 0 and not nat_c.destroyed
+    assert parallel.gather_counts(50 + rank) == [50, 51]
     chk = torch.ones(1)
     parallel.allreduce_sum_(chk)                   # the fallback transport still works
     assert float(chk) == world
@@ -193,3 +203,28 @@ def test_shard_slices_cover_everything():
                 got += list(range(n))[s]
             assert got == list(range(n))
     assert parallel.world_size() == 1 and not parallel.active()
+
+
+def test_minibatch_plan_is_identical_on_every_rank_for_ragged_shards():
+    """ceil(T*N_r / M) differs between ranks when the env shards differ by one (cfg3 over 3 ranks:
+    5462/5461/5461 envs, per-rank minibatch 5461 -> 25 vs 24 minibatches): the plan must give every rank the same
+    number of optimiser steps, non-empty minibatches, and the true global row count of each."""
+    sys.path.insert(0, os.path.join(ROOT, "constraints-as-terminations_amd"))
+    import pytest
+    from cat_envs import parallel
+    rows = [24 * 5462, 24 * 5461, 24 * 5461]
+    n_mb, m_r, per_rank, glob = parallel.minibatch_plan(rows, 16384 // 3)
+    assert n_mb == 24 and m_r == [5462, 5461, 5461]
+    assert all(len(pr) == n_mb and min(pr) >= 1 and sum(pr) == b for pr, b in zip(per_rank, rows))
+    assert glob == [sum(pr[k] for pr in per_rank) for k in range(n_mb)] and sum(glob) == sum(rows)
+    # equal shards: exactly the single-process schedule of each rank
+    n_mb, m_r, per_rank, glob = parallel.minibatch_plan([98304, 98304], 16384)
+    assert n_mb == 6 and m_r == [16384, 16384] and glob == [32768] * 6
+    # one rank: ceil(B / M) minibatches, the last one short
+    n_mb, m_r, per_rank, glob = parallel.minibatch_plan([1000], 384)
+    assert n_mb == 3 and m_r == [384] and per_rank == [[384, 384, 232]] and glob == [384, 384, 232]
+    # 2049 envs over 2 ranks x 24 steps, 4096-row minibatches
+    n_mb, m_r, per_rank, glob = parallel.minibatch_plan([24 * 1025, 24 * 1024], 4096)
+    assert n_mb == 6 and m_r == [4100, 4096] and glob == [8196] * 6
+    with pytest.raises(ValueError):
+        parallel.minibatch_plan([59, 58], 2)      # 29 minibatches of ceil(59/29) = 3 rows: rank 0 runs out after 20

@@ -279,9 +279,10 @@ def test_cfg5_32768_envs_fp16_planes_bf16_mlp_end_to_end():
     oracle; GAE bit-exact on the device's own planes after widening (fp32 recurrence, RNE to half); whole iteration
     within bf16 distance of the oracle's restatement of that arithmetic."""
     import smoke_impl
-    trainer, orc, outs = smoke_impl.run_pair(num_envs=32768, num_steps=24, minibatch=16384, epochs=1, iters=1,
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=32768, num_steps=24, minibatch=16384, epochs=5, iters=1,
                                              hidden=(256, 256, 256), six_terms=False, obs_dim=48,
                                              agent_overrides={"rollout_dtype": "fp16", "mlp_precision": "bf16"})
+    assert trainer.adam_step == 5 * 48           # the configuration's own 5 epochs x 48 minibatches
     T = trainer.T
     assert trainer.rewards.dtype == torch.float16 and trainer.advantages.dtype == torch.float16
     assert trainer.agent.shape.mfma_bf16 == 1 and trainer.sink is not None
@@ -302,8 +303,13 @@ def test_cfg5_32768_envs_fp16_planes_bf16_mlp_end_to_end():
     #     difference can flip a bf16 rounding, see test_gpu_bf16.py)
     rep = smoke_impl.compare(trainer, orc, outs[-1], check=False)
     print(rep)
+    import parity_record
+    parity_record.record("cfg5_32768x24_fp16_planes_bf16_mlp", rep,
+                         sizes=dict(num_envs=32768, num_steps=24, minibatch=16384, epochs=5, hidden=[256, 256, 256]),
+                         seed=42, note="bf16-operand GEMMs + fp16 planes vs the oracle's restatement of that arithmetic: "
+                                       "bf16-distance bars, not the fp32 ones")
     assert rep["values"] < 2e-2 and rep["logprobs"] < 2e-2 and rep["advantages"] < 5e-2, rep
-    assert rep["params"] < 2e-3, rep
+    assert rep["params"] < 4e-3, rep
     assert np.isfinite(trainer.agent.flat.cpu().numpy()).all()
 
 

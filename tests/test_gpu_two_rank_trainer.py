@@ -1,0 +1,160 @@
+"""The env-sharded ``PPOTrainer`` with TWO REAL RANKS (two processes sharing cuda:0, gloo process group) against the
+single-process CPU oracle on the union of the shards - the claim of SURVEY 8e / DESIGN 6: in ``dist_exact`` mode N ranks
+reproduce one process.  Semantic precedent in the reference: skrl/ppo.py:126-131 (parameter broadcast), :534-537
+(gradient reduction), :562-564 (KL reduction); cleanrl/ppo.py:314-318 (minibatch advantage statistics, here global).
+
+Global minibatch k of the oracle = union of the ranks' k-th local minibatches; the oracle replays the ranks' actions
+and is handed the union of their noise.  Bars: termination masks / running maxima / per-term statistics bit-exact,
+observation + value normalisers 1e-6 relative, parameters 4e-4, both ranks' parameters bit-identical to each other.
+The achieved errors are recorded in profiles/r3_parity.json (see tests/parity_record.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import dist_trainer_worker as W
+import parity_record
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(tmp_path, spec, world=2):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=W.rank_main, args=(r, world, port, str(tmp_path), spec)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+            raise AssertionError("rank process timed out")
+        assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
+    return [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(world)]
+
+
+def _check_against_union(spec, ranks, world, name, bars):
+    orc, out = W.union_oracle(spec, world, ranks, W.proto_env(spec))
+    sizes = W.shard_sizes(spec["n_total"], world)
+    offs = np.cumsum([0] + sizes)
+    T = spec["T"]
+    err = lambda a, b: float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+    rep = {k: 0.0 for k in ("rewards", "dones", "values", "logprobs", "advantages", "returns")}
+    for r, rk in enumerate(ranks):
+        sl = slice(offs[r], offs[r + 1])
+        rep["rewards"] = max(rep["rewards"], err(rk["rewards"], orc.rewards.numpy()[:, sl]))
+        rep["dones"] = max(rep["dones"], err(rk["dones"][1:T], orc.dones.numpy()[1:, sl]))
+        rep["values"] = max(rep["values"], err(rk["values"], orc.values.numpy()[:, sl]))
+        rep["logprobs"] = max(rep["logprobs"], err(rk["logprobs"], orc.logprobs.numpy()[:, sl]))
+        rep["advantages"] = max(rep["advantages"], err(rk["advantages"], out["advantages"].numpy()[:, sl]))
+        rep["returns"] = max(rep["returns"], err(rk["returns"], out["returns"].numpy()[:, sl]))
+        # CaT state: running maxima are global and bit-exact on every rank; per-term statistics per env
+        np.testing.assert_array_equal(rk["running_maxes"][0], orc.env.mgr.cat.get_running_maxes()[0])
+        for t, nm in enumerate(orc.env.mgr.term_names):
+            np.testing.assert_array_equal(rk["ep_sums"][t], orc.env.mgr.episode_sums[nm][sl])
+            np.testing.assert_array_equal(rk["ep_means"][t], orc.env.mgr.cstr_mean_values[nm][sl])
+    o_rms, v_rms = orc.agent.obs_rms.state(), orc.agent.value_rms.state()
+    rel = lambda a, b: float((np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) /
+                              (np.abs(np.asarray(b, np.float64)) + 1e-3)).max())
+    rep["obs_rms"] = max(rel(ranks[0]["obs_mean"], o_rms["running_mean"].numpy()),
+                         rel(ranks[0]["obs_var"], o_rms["running_var"].numpy()))
+    rep["value_rms"] = max(rel(ranks[0]["val_mean"], v_rms["running_mean"].numpy()),
+                           rel(ranks[0]["val_var"], v_rms["running_var"].numpy()))
+    assert float(ranks[0]["obs_count"]) == float(o_rms["count"]) and float(ranks[0]["val_count"]) == float(v_rms["count"])
+    import torch
+    flat_ref = torch.cat([p.detach().reshape(-1) for p in orc.agent.parameters()]).numpy()
+    rep["params"] = err(W.flat_params_of(ranks[0]), flat_ref)
+    # the replicas never diverge: identical all-reduced gradients, identical Adam
+    for rk in ranks[1:]:
+        np.testing.assert_array_equal(rk["flat"], ranks[0]["flat"])
+        for k in ("obs_mean", "obs_var", "val_mean", "val_var"):
+            np.testing.assert_array_equal(rk[k], ranks[0][k])
+    parity_record.record(name, rep, sizes=dict(ranks=world, envs=sizes, T=T, epochs=spec["epochs"],
+                                               iters=spec["iters"], minibatch_rows=[int(r["M"]) for r in ranks]),
+                         seed=spec["seed"])
+    print(name, rep)
+    assert rep["rewards"] <= bars.get("masks", 0.0) and rep["dones"] <= bars.get("masks", 0.0), rep
+    assert rep["obs_rms"] < bars["rms"] and rep["value_rms"] < bars["vrms"], rep
+    assert rep["values"] < bars["values"] and rep["logprobs"] < bars["logprobs"], rep
+    assert rep["advantages"] < bars["adv"] and rep["returns"] < bars["adv"], rep
+    assert rep["params"] < bars["params"], rep
+    return rep
+
+
+FP32_BARS = dict(masks=0.0, rms=1e-6, vrms=2e-5, values=4e-5, logprobs=4e-4, adv=1e-4, params=4e-4)
+
+
+def test_two_ranks_ragged_shards_equal_one_process_on_the_union(tmp_path):
+    """2049 envs -> shards of 1025 / 1024, full 13-term ConstraintsCfg, reference MLP, T = 24, 5 epochs, 2 iterations,
+    per-rank minibatches of 4096 (ragged: 4100 / 4096 rows after the plan), dist_exact, fused rollout step."""
+    spec = dict(n_total=2049, T=24, minibatch=4096, epochs=5, iters=2, hidden=(512, 256, 128), six_terms=False,
+                obs_dim=45, seed=42)
+    ranks = _run_ranks(tmp_path, spec)
+    assert [int(r["M"]) for r in ranks] == [4100, 4096] and int(ranks[0]["n_mb"]) == 6
+    assert list(ranks[0]["mb_rows_global"]) == [8196] * 6 and all(int(r["fused"]) == 1 for r in ranks)
+    assert all(int(r["adam_step"]) == 60 for r in ranks)
+    _check_against_union(spec, ranks, 2, "two_rank_ragged_2049x24_13terms", FP32_BARS)
+
+
+def test_two_ranks_at_cfg3_per_rank_shape(tmp_path):
+    """BASELINE configs[2] per-rank shape (2048 envs x 24, full constraint set, reference MLP, 2048-row minibatches,
+    5 epochs = 120 optimiser steps) on two ranks: a 4096-env job equal to one process on the union."""
+    spec = dict(n_total=4096, T=24, minibatch=2048, epochs=5, iters=1, hidden=(512, 256, 128), six_terms=False,
+                obs_dim=45, seed=7)
+    ranks = _run_ranks(tmp_path, spec)
+    assert all(int(r["M"]) == 2048 and int(r["n_mb"]) == 24 and int(r["adam_step"]) == 120 for r in ranks)
+    _check_against_union(spec, ranks, 2, "two_rank_cfg3_shape_2x2048x24", FP32_BARS)
+
+
+def test_two_ranks_unfused_env_step_path(tmp_path):
+    """the separate-call env step (a foreign env has no ``step_into``): two-phase CaT step with the MAX all-reduce,
+    moment sums through ``RunningMeanStd.dist_group``"""
+    spec = dict(n_total=257, T=8, minibatch=512, epochs=2, iters=2, hidden=(256, 256, 256), six_terms=True,
+                obs_dim=48, seed=3, overrides={"fused_rollout": False})
+    ranks = _run_ranks(tmp_path, spec)
+    assert all(int(r["fused"]) == 0 for r in ranks)
+    _check_against_union(spec, ranks, 2, "two_rank_unfused_257x8", FP32_BARS)
+
+
+def test_two_ranks_fp16_planes_exact_advantage_statistics(tmp_path):
+    """round 2 raised NotImplementedError for fp16 rollout planes + dist_exact (BASELINE configs[4] env-sharded): the
+    advantage moments now come from the gather's own chunk sums (catppo_adv_moments_parts), any plane precision"""
+    spec = dict(n_total=513, T=16, minibatch=2048, epochs=2, iters=2, hidden=(256, 256, 256), six_terms=False,
+                obs_dim=48, seed=11, overrides={"rollout_dtype": "fp16"})
+    ranks = _run_ranks(tmp_path, spec)
+    bars = dict(masks=0.0, rms=1e-6, vrms=2e-3, values=2e-3, logprobs=4e-4, adv=2e-2, params=2e-3)
+    _check_against_union(spec, ranks, 2, "two_rank_fp16_planes_513x16", bars)
+
+
+def test_two_ranks_inexact_mode_keeps_a_global_observation_normaliser(tmp_path):
+    """with dist_exact=False the fused step left the moment sums rank-local while dividing by the
+    GLOBAL env count.  Now the sums are always reduced: both ranks hold the normaliser of the union batch (checked
+    against fp64 batch moments of the union of the shards' raw observations), CaT maxima stay local by design."""
+    import torch
+    from oracle import ppo_oracle as PO
+    spec = dict(n_total=130, T=6, minibatch=256, epochs=1, iters=1, hidden=(256, 256, 256), six_terms=True,
+                obs_dim=48, seed=5, overrides={"dist_exact": False})
+    ranks = _run_ranks(tmp_path, spec)
+    assert all(int(r["fused"]) == 1 for r in ranks)
+    env = W.proto_env(spec)
+    a, w = env.sim.off["obs"]
+    obs = np.concatenate([r["stream"][:, :, a:a + w] for r in ranks], axis=1)      # (S, 130, D) raw observations
+    ref = PO.RMSOracle((w,))
+    for s in range(spec["T"] + 1):                    # reset observation + T steps
+        ref.update(torch.from_numpy(obs[s]))
+    st = ref.state()
+    for rk in ranks:
+        np.testing.assert_allclose(rk["obs_mean"], st["running_mean"].numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(rk["obs_var"], st["running_var"].numpy(), rtol=2e-6, atol=2e-6)
+        assert float(rk["obs_count"]) == float(st["count"]) == 1.0 + 130 * (spec["T"] + 1)
+    np.testing.assert_array_equal(ranks[0]["flat"], ranks[1]["flat"])
+    assert not np.array_equal(ranks[0]["running_maxes"], ranks[1]["running_maxes"])     # local maxima: documented

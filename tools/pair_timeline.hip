@@ -51,15 +51,15 @@ __global__ __launch_bounds__(256, OCC) void pair_tl(const Params p0, const Param
     }
   }
   if (kind == 0) {
-    gemm::gemm_body<BM0, BN0, false, false, gemm::EPI_PARTIAL>(p0, idx % tiles0, tiles0, idx / tiles0, smem);
+    gemm::gemm_body<BM0, BN0, false, false, gemm::EPI_PARTIAL>(p0, gemm::xcd_tile_index(idx % tiles0, tiles0), idx / tiles0, smem);
   } else if (tpb == 1) {
-    gemm::gemm_body<BM1, BN1, true, false, gemm::EPI_MUL_DELU>(p1, idx % tiles1, tiles1, idx / tiles1, smem);
+    gemm::gemm_body<BM1, BN1, true, false, gemm::EPI_MUL_DELU>(p1, gemm::xcd_tile_index(idx % tiles1, tiles1), idx / tiles1, smem);
   } else {
     // tpb consecutive tiles of this XCD's chunk per workgroup (n1 counts workgroups; both nets in one index space)
     for (int t = 0; t < tpb; ++t) {
       const int raw = (idx & 7) + 8 * (tpb * (idx >> 3) + t);      // same XCD residue, consecutive chunk positions
       const int per_net = tiles1;
-      gemm::gemm_body<BM1, BN1, true, false, gemm::EPI_MUL_DELU>(p1, raw % per_net, per_net, raw / per_net, smem);
+      gemm::gemm_body<BM1, BN1, true, false, gemm::EPI_MUL_DELU>(p1, gemm::xcd_tile_index(raw % per_net, per_net), raw / per_net, smem);
       __syncthreads();
     }
   }
