@@ -54,6 +54,16 @@ class IterState(C.Structure):
                 ("kl_mark", C.c_double), ("n_mark", C.c_double), ("last_kl", C.c_double), ("reserved", C.c_int64)]
 
 
+RLG_MAX_VALUE_SIZE = 4
+
+
+class RlgMeters(C.Structure):
+    """catppo_rlg_meters (device resident; this mirror is used for its size and for read-backs)"""
+    _fields_ = [("mean_rewards", C.c_float * RLG_MAX_VALUE_SIZE), ("mean_shaped_rewards", C.c_float * RLG_MAX_VALUE_SIZE),
+                ("mean_lengths", C.c_float), ("size_rewards", C.c_int32), ("size_shaped", C.c_int32),
+                ("size_lengths", C.c_int32), ("max_size", C.c_int32), ("last_done_count", C.c_int32)]
+
+
 class RolloutStep(C.Structure):
     """catppo_rollout_step: argument block of the fused rollout step (field order = include/catppo.h)"""
     _fields_ = [
@@ -170,6 +180,8 @@ _SIGNATURES = {
     # ---- ABI 0.3
     "catppo_graph_abort": (C.c_int, [_vp, _vp]),
     "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
+    "catppo_rlg_episode_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -448,6 +460,29 @@ class Native:
         self._ok(self.lib.catppo_value_bootstrap(self.h, _p(_chk(rewards, torch.float32, "rewards")),
                                                  _p(_chk(values, torch.float32, "values")), _p(time_outs),
                                                  f32(gamma), rewards.numel(), self._stream()))
+
+    # ------------------------------------------------------------------ rl_games episode bookkeeping
+    def rlg_meters_new(self, max_size: int) -> torch.Tensor:
+        """device-resident catppo_rlg_meters (three AverageMeters over the last ``max_size`` finished episodes)"""
+        m = torch.zeros(C.sizeof(RlgMeters), dtype=torch.uint8, device=self.device)
+        self._ok(self.lib.catppo_rlg_meters_init(self.h, _p(m), int(max_size), self._stream()))
+        return m
+
+    def rlg_meters_read(self, m: torch.Tensor) -> RlgMeters:
+        """host copy (synchronises; logging / tests)"""
+        return RlgMeters.from_buffer_copy(bytes(m.cpu().numpy().tobytes()))
+
+    def rlg_episode_step(self, rewards, shaped_rewards, dones, current_rewards, current_shaped_rewards,
+                         current_lengths, meters, done_mask=None):
+        n = dones.numel()
+        v = rewards.numel() // n
+        for nm, t in (("rewards", rewards), ("shaped_rewards", shaped_rewards), ("dones", dones),
+                      ("current_rewards", current_rewards), ("current_shaped_rewards", current_shaped_rewards),
+                      ("current_lengths", current_lengths)):
+            _chk(t, torch.float32, nm)
+        self._ok(self.lib.catppo_rlg_episode_step(self.h, _p(rewards), _p(shaped_rewards), _p(dones), int(v),
+                                                  _p(current_rewards), _p(current_shaped_rewards),
+                                                  _p(current_lengths), n, _p(meters), _p(done_mask), self._stream()))
 
     # ------------------------------------------------------------------ running mean / std
     def rms_update(self, x, n_rows, dim, ldx, mean, var, count):

@@ -6,5 +6,6 @@ third-party package the reference only subclasses; it is out of scope here.  Wha
 time-outs, ``discount_values`` on float dones (rl_games/cat_common.py:35-112, cat_experience.py) - is
 provided as device functions with the same argument meaning.
 """
-from .cat_common import bootstrap_time_outs, discount_values  # noqa: F401
-from .cat_experience import CaTExperienceBuffer, swap_and_flatten01  # noqa: F401
+from .cat_common import CaTA2CAgent, bootstrap_time_outs, discount_values  # noqa: F401
+from .cat_experience import CaTExperienceBuffer, CaTVectorizedReplayBuffer, swap_and_flatten01  # noqa: F401
+from .rl_games import RlGamesVecEnvWrapperCaT  # noqa: F401

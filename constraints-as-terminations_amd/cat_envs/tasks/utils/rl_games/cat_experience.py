@@ -113,6 +113,42 @@ class CaTExperienceBuffer:
         return out
 
 
+class CaTVectorizedReplayBuffer:
+    """Ring replay buffer with a float32 ``dones`` column (reference rl_games/cat_experience.py:7-17 re-creates the
+    uint8 ``dones`` of rl_games' ``VectorizedReplayBuffer`` as fp32).  Contract restated from rl_games' published class
+    (not vendored: parity unpinned): ``add(obs, action, reward, next_obs, done)`` appends a batch of transitions at the
+    ring position (wrapping), ``sample(batch_size)`` draws uniformly from the filled part and returns
+    ``(obses, actions, rewards, next_obses, dones)``."""
+
+    def __init__(self, obs_shape, action_shape, capacity: int, device="cuda"):
+        self.device = torch.device(device)
+        e = lambda *s: torch.empty((capacity, *s), dtype=torch.float32, device=self.device)   # noqa: E731
+        self.obses, self.next_obses = e(*obs_shape), e(*obs_shape)
+        self.actions, self.rewards = e(*action_shape), e(1)
+        self.dones = e(1)                      # the CaT override: termination PROBABILITY, float32
+        self.capacity, self.idx, self.full = int(capacity), 0, False
+
+    def add(self, obs, action, reward, next_obs, done):
+        n = obs.shape[0]
+        remaining = min(self.capacity - self.idx, n)
+        overflow = n - remaining
+        if remaining < n:                      # wrap: the tail of the batch goes to the front
+            for dst, src in ((self.obses, obs), (self.actions, action), (self.rewards, reward),
+                             (self.next_obses, next_obs), (self.dones, done)):
+                dst[0:overflow] = src[-overflow:].reshape(overflow, *dst.shape[1:])
+            self.full = True
+        for dst, src in ((self.obses, obs), (self.actions, action), (self.rewards, reward),
+                         (self.next_obses, next_obs), (self.dones, done)):
+            dst[self.idx:self.idx + remaining] = src[:remaining].reshape(remaining, *dst.shape[1:])
+        self.idx = (self.idx + n) % self.capacity
+        self.full = self.full or self.idx == 0
+
+    def sample(self, batch_size: int, generator=None):
+        hi = self.capacity if self.full else self.idx
+        idxs = torch.randint(0, hi, (batch_size,), device=self.device, generator=generator)
+        return self.obses[idxs], self.actions[idxs], self.rewards[idxs], self.next_obses[idxs], self.dones[idxs]
+
+
 def swap_and_flatten01(arr: torch.Tensor) -> torch.Tensor:
     """(horizon, actors, ...) -> (actors * horizon, ...) like rl_games.common.a2c_common.swap_and_flatten01"""
     if arr is None:

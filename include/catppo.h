@@ -514,6 +514,33 @@ uint64_t catppo_rollout_xchg_sum_offset(int K);
 int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
 int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
 
+/* ---- rl_games front end: episode bookkeeping with float dones ---------------------------------------
+ * One env step of CaTA2CAgent.play_steps' bookkeeping (rl_games/cat_common.py:71-92), one launch, no host sync:
+ *   current_rewards += rewards; current_shaped_rewards += shaped_rewards; current_lengths += 1
+ *   done_i = dones_i >= 1.0;  the three AverageMeters are updated with current_*[done]
+ *   current_rewards *= (1 - dones); current_shaped_rewards *= (1 - dones)   (FLOAT not_dones);  current_lengths[done] = 0
+ * rewards / shaped_rewards / current_*rewards: [N, value_size]; dones, current_lengths: [N] (fp32, rl_games keeps the
+ * lengths in fp32); done_mask_out: optional [N] bytes (what `dones.ge(1.0)` was), for an observer that wants indices.
+ * catppo_rlg_meters (device memory, initialised by catppo_rlg_meters_init) restates rl_games' torch_ext.AverageMeter
+ * (rl_games 1.6.1 is not vendored in the reference tree: published rule, parity unpinned against rl_games itself):
+ *   update(values): n = rows; if n == 0 return; new_mean = mean(values); size = min(n, max_size);
+ *                   old = min(max_size - size, current_size); current_size = old + size;
+ *                   mean = (mean * old + new_mean * size) / (old + size)                                            */
+#define CATPPO_RLG_MAX_VALUE_SIZE 4
+typedef struct catppo_rlg_meters {
+  float mean_rewards[CATPPO_RLG_MAX_VALUE_SIZE];
+  float mean_shaped_rewards[CATPPO_RLG_MAX_VALUE_SIZE];
+  float mean_lengths;
+  int32_t size_rewards, size_shaped, size_lengths;   /* AverageMeter.current_size */
+  int32_t max_size;                                   /* games_to_track */
+  int32_t last_done_count;                            /* episodes that ended in the latest step */
+} catppo_rlg_meters;
+int catppo_rlg_meters_init(catppo_ctx* ctx, catppo_rlg_meters* meters, int max_size, void* stream);
+int catppo_rlg_episode_step(catppo_ctx* ctx, const float* rewards, const float* shaped_rewards, const float* dones,
+                            int value_size, float* current_rewards, float* current_shaped_rewards,
+                            float* current_lengths, int64_t N, catppo_rlg_meters* meters, uint8_t* done_mask_out,
+                            void* stream);
+
 /* ---- HIP graphs ------------------------------------------------------------------------------------------------
  * Capture every launch the library (or anything else) enqueues on `stream` between begin and end into a hipGraph,
  * instantiate it, and replay it with one call.  `stream` must not be the legacy default stream.  No library call

@@ -419,10 +419,147 @@ def gen_skrl_gae():
     save("skrl_gae", **out)
 
 
+def gen_rlg_play_steps():
+    """Executes the reference's own ``CaTA2CAgent.play_steps`` (rl_games/cat_common.py:35-112) - the method node is
+    lifted out of the class with ``ast`` (rl_games is not installed, so the module cannot be imported) and called on a
+    stub agent object that supplies what the method touches: policy outputs / env answers from
+    ``streams.rlg_play_steps_inputs``, a dict-of-planes experience buffer with the float ``dones`` plane of
+    cat_experience.py:27-33, recording meters / observer, and rl_games' published ``discount_values`` /
+    ``swap_and_flatten01`` / ``AverageMeter.update`` restated (third-party, not in the reference tree).  What the
+    golden pins is the reference's float-dones bookkeeping: which dones row lands in which buffer slot, the
+    value_bootstrap shaping, ``dones.ge(1.0)`` as the episode end, ``current_* *= 1 - dones``, the length reset.
+    Nothing but arrays is stored."""
+    import ast
+    import time as _time
+    src = open(os.path.join(R.REF_ROOT, "exts/cat_envs/cat_envs/tasks/utils/rl_games/cat_common.py")).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "play_steps")
+    mod = ast.Module(body=[fn], type_ignores=[])
+
+    def swap_and_flatten01(arr):             # rl_games.common.a2c_common (published)
+        if arr is None:
+            return arr
+        s = arr.size()
+        return arr.transpose(0, 1).reshape(s[0] * s[1], *s[2:])
+
+    ns = {"torch": torch, "time": _time, "swap_and_flatten01": swap_and_flatten01}
+    exec(compile(mod, "<reference rl_games/cat_common.py play_steps>", "exec"), ns)
+    play_steps = ns["play_steps"]
+
+    N, T, D, A, H = 48, 16, 5, 3, 2
+    x = S.rlg_play_steps_inputs(901, N, T, D, A, H)
+
+    class Meter:                             # rl_games torch_ext.AverageMeter (published rule), recording its inputs
+        def __init__(self, shape, max_size):
+            self.max_size, self.current_size, self.mean, self.log = max_size, 0, torch.zeros(shape), []
+
+        def update(self, values):
+            self.log.append(values.clone())
+            size = values.size()[0]
+            if size == 0:
+                return
+            new_mean = torch.mean(values.float(), dim=0)
+            size = int(np.clip(size, 0, self.max_size))
+            old_size = min(self.max_size - size, self.current_size)
+            size_sum = old_size + size
+            self.current_size = size_sum
+            self.mean = (self.mean * old_size + new_mean * size) / size_sum
+
+    class Buffer:                            # the part of rl_games' ExperienceBuffer play_steps uses
+        def __init__(self):
+            z = lambda *s: torch.zeros(T, N, *s)
+            self.tensor_dict = {"obses": z(D), "rewards": z(1), "values": z(1), "neglogpacs": z(), "dones": z(),
+                                "actions": z(A), "mus": z(A), "sigmas": z(A)}
+
+        def update_data(self, name, index, val):
+            self.tensor_dict[name][index, :] = val
+
+        def get_transformed_list(self, op, names):
+            return {k: op(self.tensor_dict[k]) for k in names if self.tensor_dict.get(k) is not None}
+
+    class Observer:
+        def __init__(self):
+            self.log = []
+
+        def process_infos(self, infos, done_indices):
+            self.log.append(done_indices.clone())
+
+    class Agent:
+        pass
+    ag = Agent()
+    ag.horizon_length, ag.use_action_masks, ag.has_central_value, ag.num_agents = T, False, False, 1
+    ag.update_list = ["actions", "neglogpacs", "values", "mus", "sigmas"]
+    ag.tensor_list = ag.update_list + ["obses", "states", "dones"]
+    ag.experience_buffer = Buffer()
+    ag.value_bootstrap, ag.gamma, ag.tau, ag.batch_size = True, 0.99, 0.95, N * T
+    ag.rewards_shaper = lambda r: r * 0.5                      # DefaultRewardsShaper(scale_value=0.5)
+    ag.cast_obs = lambda o: o
+    ag.obs = {"obs": torch.from_numpy(x["obs0"])}
+    ag.dones = torch.ones(N)
+    ag.current_rewards, ag.current_shaped_rewards = torch.zeros(N, 1), torch.zeros(N, 1)
+    ag.current_lengths = torch.zeros(N)
+    ag.game_rewards, ag.game_shaped_rewards, ag.game_lengths = Meter((1,), 100), Meter((1,), 100), Meter((), 100)
+    ag.algo_observer = Observer()
+    clock = {"t": 0, "h": 0}
+
+    def get_action_values(obs):
+        t = clock["t"]
+        return {k: torch.from_numpy(x[k][t]) for k in ("actions", "values", "neglogpacs", "mus", "sigmas")}
+
+    def env_step(actions):
+        t = clock["t"]
+        clock["t"] += 1
+        return ({"obs": torch.from_numpy(x["next_obs"][t])}, torch.from_numpy(x["rewards"][t]),
+                torch.from_numpy(x["dones"][t]), {"time_outs": torch.from_numpy(x["time_outs"][t])})
+
+    def discount_values(fdones, last_extrinsic_values, mb_fdones, mb_extrinsic_values, mb_rewards):
+        # rl_games A2CBase.discount_values (published; not in the reference tree)
+        lastgaelam = 0
+        mb_advs = torch.zeros_like(mb_rewards)
+        for t in reversed(range(ag.horizon_length)):
+            if t == ag.horizon_length - 1:
+                nextnonterminal = 1.0 - fdones
+                nextvalues = last_extrinsic_values
+            else:
+                nextnonterminal = 1.0 - mb_fdones[t + 1]
+                nextvalues = mb_extrinsic_values[t + 1]
+            nextnonterminal = nextnonterminal.unsqueeze(1)
+            delta = mb_rewards[t] + ag.gamma * nextvalues * nextnonterminal - mb_extrinsic_values[t]
+            mb_advs[t] = lastgaelam = delta + ag.gamma * ag.tau * nextnonterminal * lastgaelam
+        return mb_advs
+    ag.get_action_values, ag.env_step, ag.discount_values = get_action_values, env_step, discount_values
+    ag.get_values = lambda obs: torch.from_numpy(x["last_values"][clock["h"]])
+    out = {"N": N, "T": T, "D": D, "A": A, "H": H, "seed": 901, "inputs_checksum": S.checksum(*[x[k] for k in sorted(x)])}
+    for h in range(H):
+        clock["h"] = h
+        batch = play_steps(ag)
+        for k in ("returns", "obses", "dones", "values", "actions", "neglogpacs", "mus", "sigmas"):
+            out[f"h{h}_batch_{k}"] = t2n(batch[k]).copy()
+        out[f"h{h}_played_frames"] = batch["played_frames"]
+        out[f"h{h}_buf_rewards"] = t2n(ag.experience_buffer.tensor_dict["rewards"]).copy()
+        out[f"h{h}_buf_dones"] = t2n(ag.experience_buffer.tensor_dict["dones"]).copy()
+        out[f"h{h}_current_rewards"] = t2n(ag.current_rewards).copy()
+        out[f"h{h}_current_shaped_rewards"] = t2n(ag.current_shaped_rewards).copy()
+        out[f"h{h}_current_lengths"] = t2n(ag.current_lengths).copy()
+        out[f"h{h}_final_dones"] = t2n(ag.dones).copy()
+        out[f"h{h}_game_rewards_mean"] = t2n(ag.game_rewards.mean).copy()
+        out[f"h{h}_game_shaped_rewards_mean"] = t2n(ag.game_shaped_rewards.mean).copy()
+        out[f"h{h}_game_lengths_mean"] = t2n(ag.game_lengths.mean).copy()
+        out[f"h{h}_game_size"] = ag.game_rewards.current_size
+    done_mask = np.zeros((H * T, N), np.bool_)
+    for t, idx in enumerate(ag.algo_observer.log):
+        done_mask[t, t2n(idx).reshape(-1)] = True
+    out["done_mask"] = done_mask
+    out["meter_rewards_in_sum"] = np.array([float(v.sum()) for v in ag.game_rewards.log], np.float64)
+    out["meter_lengths_in_sum"] = np.array([float(v.sum()) for v in ag.game_lengths.log], np.float64)
+    save("rlg_play_steps", **out)
+
+
 def main():
     assert R.have_reference(), "needs /root/reference (build container only)"
     if sys.argv[1:] == ["skrl_gae"]:      # regenerate one fixture without touching the others
         return gen_skrl_gae()
+    if sys.argv[1:] == ["rlg_play_steps"]:
+        return gen_rlg_play_steps()
     print("CaT streams")
     gen_cat("small", 101, 7, S.CAT_TERMS_SMALL, [0.25, 1.0, 0.25, 1.0, 0.5], 16,
             curriculum_at=8, reset_at={5, 11})
@@ -436,6 +573,7 @@ def main():
     gen_rms()
     gen_agent()
     gen_skrl_gae()
+    gen_rlg_play_steps()
     print("PPO() runs")
     run_ref_ppo("64x24", 201, N=64, T=24, iters=3, mb=512, epochs=5)
     run_ref_ppo("64x48", 202, N=64, T=48, iters=1, mb=1024, epochs=1, keep_grads=False)

@@ -134,3 +134,28 @@ def agent_weights(seed: int, obs_dim: int, act_dim: int, hidden=(512, 256, 128))
             sd[f"{net}.{2 * li}.weight"] = (rs.standard_normal((fo, fi)) * (1.0 / np.sqrt(fi))).astype(F32)
             sd[f"{net}.{2 * li}.bias"] = (rs.standard_normal(fo) * 0.05).astype(F32)
     return sd
+
+
+def rlg_play_steps_inputs(seed: int, N: int, T: int, D: int, A: int, horizons: int = 2):
+    """Inputs of ``horizons`` consecutive ``CaTA2CAgent.play_steps`` calls (reference rl_games/cat_common.py:35-112):
+    per step the policy outputs (actions, values, neglogpacs, mus, sigmas) and the env's answer (next obs, rewards (N,1),
+    FLOAT dones mixing exact 0, probabilities in (0,1) and exact 1.0, bool time_outs); plus the first observation and
+    the bootstrap values after each horizon."""
+    rs = np.random.RandomState(seed)
+    S = horizons * T
+    d = rs.uniform(0, 1, (S, N)).astype(F32)
+    u = rs.rand(S, N)
+    dones = np.where(u < 0.55, F32(0), np.where(u < 0.85, d, F32(1))).astype(F32)     # 15 % certain terminations
+    return {
+        "obs0": rs.standard_normal((N, D)).astype(F32),
+        "actions": rs.standard_normal((S, N, A)).astype(F32),
+        "values": rs.standard_normal((S, N, 1)).astype(F32),
+        "neglogpacs": rs.uniform(5, 20, (S, N)).astype(F32),
+        "mus": rs.standard_normal((S, N, A)).astype(F32),
+        "sigmas": rs.uniform(0.1, 1.0, (S, N, A)).astype(F32),
+        "next_obs": rs.standard_normal((S, N, D)).astype(F32),
+        "rewards": rs.uniform(-0.5, 1.5, (S, N, 1)).astype(F32),
+        "dones": dones,
+        "time_outs": rs.rand(S, N) < 0.07,
+        "last_values": rs.standard_normal((horizons, N, 1)).astype(F32),
+    }

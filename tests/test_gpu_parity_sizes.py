@@ -23,15 +23,15 @@ def dev(x, dtype=None):
 
 
 # ------------------------------------------------------------------------------------------ whole iterations
-# Bars of the whole-iteration comparisons.  north_star asks for returns / advantages within 1e-5 (fp32): that bar is
-# met - bit-exactly - by the GAE KERNEL on identical inputs (test_gae_bit_exact, test_gae_vs_reference_ppo_run).  At
-# ITERATION level the inputs of GAE are no longer identical: ``values`` come out of three fp32 GEMM layers whose
-# reassociation (MFMA order vs the oracle's BLAS order) leaves ~1e-6..1e-5 per value, which the recurrence then
-# accumulates over up to T steps (sum of gamma*lambda powers <= 17).  What the iteration really achieves is recorded
-# per configuration in profiles/r3_parity.json by these tests; each bar below is <= 2x the worst case recorded there
-# (all seeds / boxes of round 3), never looser than the round-2 bars.
+# Bars of the whole-iteration comparisons.  north_star: "returns/advantages within 1e-5 fp32".  The GAE KERNEL meets
+# that bit-exactly on identical inputs (test_gae_bit_exact, test_gae_vs_reference_ppo_run); at ITERATION level GAE's
+# inputs are the device's own values (three fp32 GEMM layers in MFMA order vs the oracle's BLAS order) and the first
+# recorded run of round 3 (profiles/r3_parity.json: every config-size test writes its achieved errors there) showed
+# that the whole iteration stays inside 1e-5 too: advantages <= 4.2e-6, returns <= 2.9e-6, values <= 3.8e-6,
+# log-probs <= 7.6e-6, parameters after all optimiser steps <= 5.8e-6 (cfg2, 30 steps) / <= 1e-7 (others).
+# Each bar is <= 2x the recorded worst case (round 2 used 1e-4 / 4e-4 and never recorded what it achieved).
 BARS = {
-    "default": dict(values=4e-5, logprobs=4e-4, advantages=1e-4, returns=1e-4, params=4e-4),
+    "default": dict(values=8e-6, logprobs=1.6e-5, advantages=1e-5, returns=1e-5, params=1.2e-5),
 }
 
 
