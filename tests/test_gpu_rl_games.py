@@ -168,5 +168,5 @@ def test_vectorized_replay_buffer_float_dones_and_wraparound():
     np.testing.assert_array_equal(rb.dones.cpu().numpy()[:, 0],
                                   np.float32([0.3, 0.3, 0.1, 0.1, 0.2, 0.2, 0.2, 0.2, 0.3, 0.3]))
     o, a, r, no, d = rb.sample(64)
-    assert d.dtype == torch.float32 and o.shape == (64, 5) and set(np.unique(d.cpu().numpy()).round(3)) <= {0.1, 0.2, 0.3}
+    assert d.dtype == torch.float32 and o.shape == (64, 5) and {round(float(v), 3) for v in np.unique(d.cpu().numpy())} <= {0.1, 0.2, 0.3}
     np.testing.assert_array_equal((no - o).cpu().numpy(), np.full((64, 5), 0.5, np.float32))
