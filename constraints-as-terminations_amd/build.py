@@ -68,6 +68,26 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
     return LIB
 
 
+def build_variant(name: str, extra_flags, verbose: bool = False) -> str:
+    """A/B builds of the library (tools/gpu_ab.sh, CATPPO_LIB): the same sources with extra compile flags, e.g.
+    ``build_variant("nopipe", ["-DGEMM_PIPE=0"])`` -> tools/bin/libcatppo_nopipe.so (git-ignored, travels with gpurun)"""
+    objdir = os.path.join(OBJDIR, "variant_" + name)
+    outdir = os.path.join(ROOT, "tools", "bin")
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(outdir, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    jobs = [[HIPCC, *HIP_FLAGS, *extra_flags, "-c", os.path.join(CSRC, s), "-o", os.path.join(objdir, s[:-4] + ".o")]
+            for s in srcs]
+    with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
+        for out in ex.map(_run, jobs):
+            if verbose and out.strip():
+                print(out)
+    lib = os.path.join(outdir, f"libcatppo_{name}.so")
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib,
+          *[os.path.join(objdir, s[:-4] + ".o") for s in srcs]])
+    return lib
+
+
 def build_oracle_c(force: bool = False) -> str | None:
     if not os.path.exists(ORACLE_C):
         return None
@@ -78,6 +98,9 @@ def build_oracle_c(force: bool = False) -> str | None:
 
 
 if __name__ == "__main__":
+    if len(sys.argv) >= 3 and sys.argv[1] == "--variant":       # build.py --variant NAME [flags...]
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+        sys.exit(0)
     force = "--force" in sys.argv
     print(build_hip(force))
     print(build_oracle_c(force))

@@ -24,12 +24,18 @@
 
 #include "common.h"
 
+#include <type_traits>
+
 namespace gemm {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int BK = 16;             // default contraction slab; kernels take it as the BKT template parameter
+
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 1                // 0: the round-2 main loop (A/B builds: tools/gpu_ab.sh)
+#endif
 
 enum Epilogue {
   EPI_BIAS_ELU = 0,  // C = elu(acc + bias[j])                       forward hidden layer
@@ -138,7 +144,38 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
 
   float4 ra[A_LD4], rb[B_LD4];
 
-  auto gload = [&](int k0) {
+  // Interior tiles (every row / column of the tile in bounds: all of them at the BASELINE shapes) take branch-free
+  // loads through per-thread pointers that advance by one slab per iteration; edge tiles and the last, partial slab
+  // of a contraction keep the guarded loads.  (The guarded form costs a saveexec / branch pair and a zero fill per
+  // 16-B load: ~60 issue slots per slab that sat between the barrier and the first ds_read of every slab.)
+  const bool interior = (i0 + BM <= p.I) && (j0 + BN <= p.J);
+  // address = workgroup-uniform base (SGPR pair, advanced by one slab per iteration) + per-thread 32-bit byte offset:
+  // the `saddr + voffset` form of global_load - one VGPR per 16-B load instead of a 64-bit pointer each
+  const char* abase = reinterpret_cast<const char*>(A_KC ? op.A + (int64_t)i0 * p.lda : op.A + i0);
+  const char* bbase = reinterpret_cast<const char*>(B_KC ? op.B + (int64_t)j0 * p.ldb : op.B + j0);
+  uint32_t aoff[A_LD4], boff[B_LD4];
+#pragma unroll
+  for (int q = 0; q < A_LD4; ++q) {
+    const int f = tid + q * 256;
+    aoff[q] = 4u * (A_KC ? (uint32_t)(f / KQ) * (uint32_t)p.lda + 4u * (f % KQ)
+                         : (uint32_t)(f / (BM / 4)) * (uint32_t)p.lda + 4u * (f % (BM / 4)));
+  }
+#pragma unroll
+  for (int q = 0; q < B_LD4; ++q) {
+    const int f = tid + q * 256;
+    boff[q] = 4u * (B_KC ? (uint32_t)(f / KQ) * (uint32_t)p.ldb + 4u * (f % KQ)
+                         : (uint32_t)(f / (BN / 4)) * (uint32_t)p.ldb + 4u * (f % (BN / 4)));
+  }
+  const int64_t a_step = 4 * (A_KC ? (int64_t)1 : (int64_t)p.lda), b_step = 4 * (B_KC ? (int64_t)1 : (int64_t)p.ldb);   // bytes per unit of k
+
+  auto gload = [&](int k0, auto fast_c) {
+    if constexpr (decltype(fast_c)::value) {     // whole tile and whole slab in bounds: straight-line loads
+#pragma unroll
+      for (int q = 0; q < A_LD4; ++q) ra[q] = *reinterpret_cast<const float4*>(abase + k0 * a_step + aoff[q]);
+#pragma unroll
+      for (int q = 0; q < B_LD4; ++q) rb[q] = *reinterpret_cast<const float4*>(bbase + k0 * b_step + boff[q]);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < A_LD4; ++q) {
       const int f = tid + q * 256;
@@ -211,7 +248,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
 
   const int n_slabs = (k_end - k_begin + BK - 1) / BK;
   if (n_slabs > 0) {
-    gload(k_begin);
+    gload(k_begin, std::false_type{});
     lstore(0);
   }
   __syncthreads();
@@ -237,9 +274,14 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
 #ifdef GEMM_TIMELINE
   if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 1] = clock64();
 #endif
+  // Two copies of the main loop: interior tiles whose contraction range is a whole number of slabs run one with
+  // straight-line global loads (no guard, no branch: the compiler otherwise merges the guarded and the unguarded load
+  // sequences into one CFG and drains vmcnt between them); everything else runs the guarded copy.
+  auto main_loop = [&](auto fast_c) {
   for (int s = 0; s < n_slabs; ++s) {
     const int cur = s & 1;
-    if (s + 1 < n_slabs) gload(k_begin + (s + 1) * BK);
+    constexpr bool kPiped = PREC == 0 && BK == 16 && GEMM_PIPE && A_KC && B_KC;     // see the pipelined slab below
+    if (!kPiped && s + 1 < n_slabs) gload(k_begin + (s + 1) * BK, fast_c);
     const float* a = As + cur * A_TILE;
     const float* b = Bs + cur * B_TILE;
 
@@ -277,7 +319,51 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
         }
       }
     };
-    if constexpr (PREC == 0) {
+    if constexpr (kPiped) {
+      // Software-pipelined slab (fp32 MFMA, 16-k slabs).  v_mfma_f32_32x32x2_f32 occupies the matrix pipe for 64
+      // cycles, so ~15 other instructions issue for free behind each one - but only if they sit BETWEEN the MFMAs in
+      // program order (a wave issues in order).  The round-1/2 loop ran   barrier -> [guarded global loads of the next
+      // slab: ~60 slots] -> 8 ds_read -> wait -> 32 MFMA -> vmcnt(0) -> 4 ds_write -> lgkmcnt(0) -> barrier : everything
+      // outside the MFMA block is a gap in which this wave feeds nothing to the pipe (~800 of ~2900 cycles per slab;
+      // the co-resident workgroup only covers it when the two happen to be out of phase).  Here:
+      //   barrier -> 8 ds_read (whole slab) -> global loads (issue while the reads are in flight) -> 24 MFMA
+      //           -> vmcnt(0) + 4 ds_write into the OTHER buffer -> 8 MFMA (cover the write latency) -> barrier
+      // What stays exposed per slab: the barrier skew and one LDS read latency.
+      float af[2][TM][4], bf[2][TN][4];
+      frag_a(0, af[0]);
+      frag_b(0, bf[0]);
+      frag_a(1, af[1]);
+      frag_b(1, bf[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < n_slabs) gload(k_begin + (s + 1) * BK, fast_c);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][tm][q], bf[0][tn][q], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][tm][q], bf[1][tn][q], acc[tm][tn], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < n_slabs) lstore(cur ^ 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 2; q < 4; ++q)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][tm][q], bf[1][tn][q], acc[tm][tn], 0, 0, 0);
+      __syncthreads();
+      continue;
+    } else if constexpr (PREC == 0) {
 #pragma unroll
       for (int blk = 0; blk < BK / 8; ++blk) {
         float af[TM][4], bf[TN][4];
@@ -352,6 +438,10 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
     if (s + 1 < n_slabs) lstore(cur ^ 1);
     __syncthreads();
   }
+  };
+  constexpr bool kPipedLoop = PREC == 0 && BK == 16 && GEMM_PIPE && A_KC && B_KC;
+  if (kPipedLoop && interior && (k_end - k_begin) % BK == 0) main_loop(std::true_type{});
+  else main_loop(std::false_type{});
 
 #ifdef GEMM_TIMELINE
   if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 2] = clock64();
