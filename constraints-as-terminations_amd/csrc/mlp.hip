@@ -471,6 +471,348 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------- fused small-batch forward
+// The whole policy / value forward of ONE network for 32 rows in one workgroup: every hidden layer and the head.
+// At rollout size (4096 envs) the layer-wise path is 3 GEMM launches + head_act = ~48 us for 2.4 GFLOP (0.31 of the
+// fp32-MFMA peak): every launch is one round of small workgroups whose prologue / epilogue / boundary nothing overlaps.
+// Here M/32 x 2 workgroups (one per CU at 4096 rows) keep their activation tile in LDS from layer to layer and stream
+// the weights (L2 resident: every CU reads the same slabs) through a three-slot LDS ring:
+//   iteration s:  MFMAs of slab s on fragments already in registers | ds_read the fragments of slab s+1 (slot written
+//                 one barrier ago) | ds_write slab s+2 from the staging registers | global_load slab s+3 | barrier
+// so the matrix pipe only ever waits for the barrier itself.  One wave per SIMD can keep the fp32 MFMA pipe full
+// (64 cycles per v_mfma_f32_32x32x2_f32, ~15 issue slots behind each), which is why 1 workgroup per CU is enough here.
+// Contraction order = gemm_body's (slab, 8-k block, lane half, step): results are bit-identical to the layer-wise path.
+#ifdef FUSED_TL   // tools/fused_fwd_timeline.py: thread 0 of every workgroup stamps the wall clock at the phase boundaries
+__device__ unsigned long long* g_fftl;    // [2 nets][1024 workgroups][16 stamps]
+#define FF_TL(i) do { if (threadIdx.x == 0 && g_fftl) { g_fftl[(blockIdx.y * 1024 + blockIdx.x) * 16 + (i)] = wall_clock64(); \
+      if ((i) == 2 || (i) == 3) g_fftl[(blockIdx.y * 1024 + blockIdx.x) * 16 + 8 + (i)] = clock64(); } } while (0)
+#else
+#define FF_TL(i) do { } while (0)
+#endif
+constexpr int kFR = 32;            // rows per workgroup
+constexpr int kFT = 512;           // threads per workgroup: eight waves (one 32-column strip of a 256-column chunk each)
+constexpr int kFWS = 20;           // floats per weight-slab row in LDS (16 k + 4 pad: conflict-free ds_read_b128)
+constexpr int kFRing = 3 * 256 * kFWS;
+
+struct FusedFwdArgs {
+  const float* x;                  // [M, Dp]
+  const float* params;
+  int64_t M;
+  int Dp, n_hidden;
+  int hidden[CATPPO_MAX_HIDDEN];
+  int64_t off_w[2][CATPPO_MAX_HIDDEN + 1], off_b[2][CATPPO_MAX_HIDDEN + 1];
+  int net0;                        // network of blockIdx.y == 0 (0 critic, 1 actor)
+  int ld0, ld1;                    // row strides (floats) of the two LDS activation tiles
+  float* Hout[2][CATPPO_MAX_HIDDEN];   // [net][layer] global copy of the activations (training) or null
+  // head (rollout), as head_act_kernel
+  const float *logstd, *eps, *given;
+  int A;
+  float *action, *logprob;
+  void* value_out;
+  int value_f16;
+  const catppo_iter_state* rng_state;
+  int rng_step;
+  float* eps_out;
+  int do_head;
+};
+
+// Heads of the fused forward on the 32-row tile in LDS.  head_act_kernel gives every row a whole wave (the launch has
+// thousands of waves to hide the Philox / Box-Muller / log-prob latency behind); a fused workgroup has four waves and
+// 32 rows, so the wave-per-row form costs 8 serial rows of ~2500 dependent cycles each (8 us of a 45 us kernel).  Here
+// the work is spread over items: actor = (row, action slot) with the 16 slots of a row in 16 adjacent lanes (two items
+// per thread), critic = (row, eighth of the contraction) with 8 lanes per row.
+template <int HL>
+__device__ __forceinline__ void fused_head(const FusedFwdArgs& a, const float* __restrict__ hs, int ld, int net,
+                                           int64_t r0, float* __restrict__ wlds) {
+  constexpr int WL = HL + 4;                       // padded weight rows: 16 slots read the same column without conflicts
+  const int tid = threadIdx.x;
+  const int nl = a.n_hidden, A = a.A;
+  const float* W4 = a.params + a.off_w[net][nl];
+  const float* b4 = a.params + a.off_b[net][nl];
+  const int n_out = net == 1 ? A : 1;
+  for (int o = tid; o < 16 * HL; o += kFT) {
+    const int k = o / HL, c = o - k * HL;
+    wlds[k * WL + c] = k < n_out ? W4[o] : 0.0f;
+  }
+  __syncthreads();
+  if (net == 0) {
+    const int r = tid >> 4, part = tid & 15;       // 16 lanes per row, HL / 16 columns each
+    const int64_t i = r0 + r;
+    const float* hp = hs + r * ld + part * (HL / 16);
+    const float* wp = wlds + part * (HL / 16);
+    float d0 = 0.0f, d1 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < HL / 16; c += 8) {
+      const float4 h0 = *reinterpret_cast<const float4*>(hp + c), h1 = *reinterpret_cast<const float4*>(hp + c + 4);
+      const float4 w0 = *reinterpret_cast<const float4*>(wp + c), w1 = *reinterpret_cast<const float4*>(wp + c + 4);
+      d0 = fmaf(h0.x, w0.x, d0), d0 = fmaf(h0.y, w0.y, d0), d0 = fmaf(h0.z, w0.z, d0), d0 = fmaf(h0.w, w0.w, d0);
+      d1 = fmaf(h1.x, w1.x, d1), d1 = fmaf(h1.y, w1.y, d1), d1 = fmaf(h1.z, w1.z, d1), d1 = fmaf(h1.w, w1.w, d1);
+    }
+    float d = d0 + d1;
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    d += __shfl_xor(d, 8, 64);
+    const float v = d + b4[0];
+    if (part == 0 && i < a.M) {
+      if (a.value_f16) reinterpret_cast<_Float16*>(a.value_out)[i] = (_Float16)v;
+      else reinterpret_cast<float*>(a.value_out)[i] = v;
+    }
+    return;
+  }
+  const int k = tid & 15;                          // action slot of this thread (both items)
+  const bool kin = k < A;
+  const float sd = kin ? expf(a.logstd[k]) : 1.0f;
+  const float var = sd * sd, lsd = logf(sd);
+  const float ba = kin ? b4[k] : 0.0f;
+  uint32_t rk0 = 0, rk1 = 0, rit = 0;
+  if (a.rng_state != nullptr) {
+    const uint64_t sd64 = a.rng_state->seed;
+    rk0 = (uint32_t)sd64, rk1 = (uint32_t)(sd64 >> 32), rit = (uint32_t)a.rng_state->iteration;
+  }
+  {
+    const int r = tid >> 4;                        // one (row, slot) item per thread
+    const int64_t i = r0 + r;
+    const bool mine = kin && i < a.M;
+    const float* hp = hs + r * ld;
+    const float* wp = wlds + k * WL;
+    float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+#pragma unroll 4
+    for (int c = 0; c < HL; c += 16) {
+      const float4 h0 = *reinterpret_cast<const float4*>(hp + c), h1 = *reinterpret_cast<const float4*>(hp + c + 4);
+      const float4 h2 = *reinterpret_cast<const float4*>(hp + c + 8), h3 = *reinterpret_cast<const float4*>(hp + c + 12);
+      const float4 w0 = *reinterpret_cast<const float4*>(wp + c), w1 = *reinterpret_cast<const float4*>(wp + c + 4);
+      const float4 w2 = *reinterpret_cast<const float4*>(wp + c + 8), w3 = *reinterpret_cast<const float4*>(wp + c + 12);
+      d0 = fmaf(h0.x, w0.x, d0), d0 = fmaf(h0.y, w0.y, d0), d0 = fmaf(h0.z, w0.z, d0), d0 = fmaf(h0.w, w0.w, d0);
+      d1 = fmaf(h1.x, w1.x, d1), d1 = fmaf(h1.y, w1.y, d1), d1 = fmaf(h1.z, w1.z, d1), d1 = fmaf(h1.w, w1.w, d1);
+      d2 = fmaf(h2.x, w2.x, d2), d2 = fmaf(h2.y, w2.y, d2), d2 = fmaf(h2.z, w2.z, d2), d2 = fmaf(h2.w, w2.w, d2);
+      d3 = fmaf(h3.x, w3.x, d3), d3 = fmaf(h3.y, w3.y, d3), d3 = fmaf(h3.z, w3.z, d3), d3 = fmaf(h3.w, w3.w, d3);
+    }
+    const float mu = ((d0 + d1) + (d2 + d3)) + ba;
+    float act = mu;
+    if (mine && a.given != nullptr) {
+      act = a.given[i * A + k];
+    } else if (mine && a.rng_state != nullptr) {
+      const rng::u32x4 blk = rng::philox4x32_10(rng::u32x4{(uint32_t)i, (uint32_t)(k >> 2), (uint32_t)a.rng_step, rit},
+                                                rk0, rk1);
+      const float e = rng::box_muller_pick(blk, k & 3);
+      act = mu + sd * e;
+      if (a.eps_out != nullptr) a.eps_out[i * A + k] = e;
+    } else if (mine && a.eps != nullptr) {
+      act = mu + sd * a.eps[i * A + k];             // Normal.sample(): loc + scale * N(0,1)
+    }
+    const float diff = act - mu;
+    float lp = kin ? (-(diff * diff) / (2.0f * var) - lsd - kHalfLog2Pi) : 0.0f;
+    lp += __shfl_xor(lp, 1, 64);                   // the 16 slots of a row sit in 16 adjacent lanes
+    lp += __shfl_xor(lp, 2, 64);
+    lp += __shfl_xor(lp, 4, 64);
+    lp += __shfl_xor(lp, 8, 64);
+    if (mine) a.action[i * A + k] = act;
+    if (k == 0 && i < a.M) a.logprob[i] = lp;
+  }
+}
+
+// one chunk of NC (256 or 128) output columns of one layer for the workgroup's 32 rows: out[:, c0 + ...] = elu(in . W^T
+// + b).  Eight waves: wave w owns columns [32 w, 32 w + 32) of the chunk (a 128-column chunk occupies waves 0-3 only).
+// W = the chunk's first weight row.  What the measurements of round 3 left standing (tools/fused_fwd_timeline.py with the
+// -DFUSED_EXP_* switches, tools/mfma_rate_probe.hip):
+//  * no workgroup barrier inside the contraction: every wave streams the weight rows of ITS OWN 32 columns (2 KB per
+//    16-k slab: lane -> row lane / 4 (+16), k quad lane % 4, four lanes per 64-B row segment) through a wave-private
+//    three-slot LDS ring; the only LDS hand-off is from a wave to itself (LDS operations of one wave execute in
+//    order), the activation tile is read-only during a layer, and the eight waves drift instead of meeting per slab;
+//  * the eight MFMAs of a slab are issued BACK TO BACK and everything else (fragments of the next slab, ring <- the
+//    staged slab, the next request) in one block behind them: the probe shows one wave with ONE accumulator sustaining
+//    142 TFLOP/s of v_mfma_f32_32x32x2_f32 when nothing sits between the MFMAs, so neither a second accumulator nor a
+//    second wave per SIMD is needed for the matrix pipe (both were tried: no change);
+//  * the loop body is guard free (~22 instructions per slab): the first version guarded every stage of every slab and
+//    copied prefetched fragments - 185 instructions per slab and wave, ISSUE bound at 2070 cycles per slab; the
+//    pipeline now simply runs past the end (the last iterations stage up to three slabs nobody multiplies: weight rows
+//    are followed by more parameters in the flat buffer, the fragments read past K stay inside the LDS allocation);
+//  * deeper weight prefetch (three staging register sets, inline-asm loads with exact vmcnt) changed nothing - the
+//    requests are L2 hits that arrive within a slab - and was removed again.
+// One accumulator, contraction order = gemm_body's (slab, 8-k block, lane half, step): bit-identical to the layer-wise path.
+template <int NC>
+__device__ __forceinline__ void fused_chunk(const float* __restrict__ in, const int ldin, float* __restrict__ out,
+                                            const int ldout, float* __restrict__ ring, const float* __restrict__ W,
+                                            const float* __restrict__ bias_c, const int c0, const int K) {
+  using gemm::f32x16;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (NC == 128 && wave >= 4) return;                        // wave-uniform: nothing to do in a 128-column chunk
+  const int n_slabs = K / 16;
+  const float bias = bias_c[wave * 32 + l31];                // requested before the contraction, used after it
+  float* const wring = ring + wave * (3 * 32 * kFWS);
+  const float* gp = W + (int64_t)(wave * 32 + (lane >> 2)) * K + 4 * (lane & 3);     // this lane's element of slab 0
+  const int64_t gq = (int64_t)16 * K;                        // 64 lanes = 16 rows further per load
+  float* const s0 = wring + (lane >> 2) * kFWS + 4 * (lane & 3);
+  float4 w0, w1;                                             // staging registers: one slab in flight
+#define FUSED_GL()                                                                        \
+  do {                                                                                    \
+    w0 = *reinterpret_cast<const float4*>(gp);                                            \
+    w1 = *reinterpret_cast<const float4*>(gp + gq);                                       \
+    gp += 16;                                                                             \
+  } while (0)
+#define FUSED_ST(slot_)                                                                   \
+  do {                                                                                    \
+    float* dp = s0 + (slot_) * (32 * kFWS);                                               \
+    *reinterpret_cast<float4*>(dp) = w0;                                                  \
+    *reinterpret_cast<float4*>(dp + 16 * kFWS) = w1;                                      \
+  } while (0)
+  float4 a0, a1, b0, b1;          // fragments of the slab being multiplied: A / B of its two 8-k blocks
+  const float* ap = in + l31 * ldin + 4 * h;                                   // A fragments: k advances 16 per slab
+  const float* const bp = wring + l31 * kFWS + 4 * h;                           // B fragments inside a ring slot
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#ifdef FUSED_EXP_NOMFMA      // timing experiments (tools/fused_fwd_timeline.py): wrong results, never in the product build
+#define FUSED_MM(av, bv) acc[0] += (av) * (bv)
+#else
+#define FUSED_MM(av, bv) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0)
+#endif
+#ifdef FUSED_EXP_NOLOAD
+#define FUSED_DO_LOAD 0
+#else
+#define FUSED_DO_LOAD 1
+#endif
+  // one slab whose ring slot is SL (static, the loop is unrolled by three): its MFMAs, then the fragments of the next
+  // slab (slot SL+1) into the same registers, ring slot SL+2 <- the staged slab, request of the slab after that
+#define FUSED_SLAB(SL)                                                                    \
+  do {                                                                                    \
+    FUSED_MM(a0.x, b0.x);                                                                 \
+    FUSED_MM(a0.y, b0.y);                                                                 \
+    FUSED_MM(a0.z, b0.z);                                                                 \
+    FUSED_MM(a0.w, b0.w);                                                                 \
+    FUSED_MM(a1.x, b1.x);                                                                 \
+    FUSED_MM(a1.y, b1.y);                                                                 \
+    FUSED_MM(a1.z, b1.z);                                                                 \
+    FUSED_MM(a1.w, b1.w);                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    ap += 16;                                                                             \
+    a0 = *reinterpret_cast<const float4*>(ap);                                            \
+    a1 = *reinterpret_cast<const float4*>(ap + 8);                                        \
+    b0 = *reinterpret_cast<const float4*>(bp + (((SL) + 1) % 3) * (32 * kFWS));           \
+    b1 = *reinterpret_cast<const float4*>(bp + (((SL) + 1) % 3) * (32 * kFWS) + 8);       \
+    if (FUSED_DO_LOAD) {                                                                  \
+      FUSED_ST(((SL) + 2) % 3);                                                           \
+      FUSED_GL();                                                                         \
+    }                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+  } while (0)
+  // prologue: slabs 0 and 1 into the ring, slab 2 requested
+  FUSED_GL();
+  FUSED_ST(0);
+  FUSED_GL();
+  FUSED_ST(1);
+  FUSED_GL();
+  a0 = *reinterpret_cast<const float4*>(ap);
+  a1 = *reinterpret_cast<const float4*>(ap + 8);
+  b0 = *reinterpret_cast<const float4*>(bp);
+  b1 = *reinterpret_cast<const float4*>(bp + 8);
+  int s = 0;
+  for (; s + 3 <= n_slabs; s += 3) {
+    FUSED_SLAB(0);              // slab s   : ring slot 2 <- slab s+2, request s+3
+    FUSED_SLAB(1);              // slab s+1 : ring slot 0 <- slab s+3, request s+4
+    FUSED_SLAB(2);              // slab s+2 : ring slot 1 <- slab s+4, request s+5
+  }
+  if (s < n_slabs) FUSED_SLAB(0);
+  if (s + 1 < n_slabs) FUSED_SLAB(1);
+#undef FUSED_SLAB
+#undef FUSED_DO_LOAD
+#undef FUSED_GL
+#undef FUSED_ST
+#undef FUSED_MM
+  // bias + ELU -> output tile.  acc[r] of a lane: row (r&3) + 8 (r>>2) + 4 h, column l31
+  const int cc = wave * 32 + l31;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+    out[row * ldout + c0 + cc] = gemm::elu_f(acc[r] + bias);
+  }
+}
+
+__global__ __launch_bounds__(kFT) void fused_fwd_kernel(const FusedFwdArgs a) {
+  using gemm::f32x16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act0 = smem;
+  float* act1 = act0 + kFR * a.ld0;
+  float* ring = act1 + kFR * a.ld1;                       // [3][256][kFWS]
+  const int net = a.net0 + blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * kFR;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  FF_TL(0);
+  // touch this wave's first weight rows of layer 0 now: the observation tile below costs one memory round trip anyway,
+  // and the contraction's own first requests then find the lines close by instead of paying a second, serial one
+  float4 warm0, warm1;
+  {
+    const float* w0p = a.params + a.off_w[net][0] + (int64_t)(wave * 32 + (lane >> 2)) * a.Dp + 4 * (lane & 3);
+    warm0 = *reinterpret_cast<const float4*>(w0p);
+    warm1 = *reinterpret_cast<const float4*>(w0p + (int64_t)16 * a.Dp);
+  }
+  {   // observation tile -> act0 (rows past M are zero: their results are never stored)
+    const int q4 = a.Dp / 4;
+    for (int f = tid; f < kFR * q4; f += kFT) {
+      const int r = f / q4, q = f - r * q4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r0 + r < a.M) v = *reinterpret_cast<const float4*>(a.x + (r0 + r) * a.Dp + 4 * q);
+      *reinterpret_cast<float4*>(act0 + r * a.ld0 + 4 * q) = v;
+    }
+  }
+  __syncthreads();
+  asm volatile("" ::"v"(warm0.x), "v"(warm1.x));       // keeps the two warm-up loads
+  FF_TL(1);
+
+  float* in = act0;
+  float* out = act1;
+  int ldin = a.ld0, ldout = a.ld1;
+  int K = a.Dp;
+  for (int l = 0; l < a.n_hidden; ++l) {
+    const int N = a.hidden[l];
+    const float* Wl = a.params + a.off_w[net][l];
+    const float* bl = a.params + a.off_b[net][l];
+    for (int c0 = 0; c0 < N; c0 += 256) {
+      if (N - c0 >= 256) fused_chunk<256>(in, ldin, out, ldout, ring, Wl + (int64_t)c0 * K, bl + c0, c0, K);
+      else fused_chunk<128>(in, ldin, out, ldout, ring, Wl + (int64_t)c0 * K, bl + c0, c0, K);   // 128 columns left
+    }
+    __syncthreads();
+    float* hg = a.Hout[blockIdx.y][l];
+    if (hg != nullptr) {     // training: the activations also go to memory (backward reads them)
+      const int q4 = N / 4;
+      for (int f = tid; f < kFR * q4; f += kFT) {
+        const int r = f / q4, q = f - r * q4;
+        if (r0 + r < a.M) {
+          const float4 v = *reinterpret_cast<const float4*>(out + r * ldout + 4 * q);
+          const float o[4] = {v.x, v.y, v.z, v.w};
+          store_vec_wt<4>(hg + (r0 + r) * N + 4 * q, o);
+        }
+      }
+    }
+    float* t = in;
+    in = out, out = t;
+    const int tl = ldin;
+    ldin = ldout, ldout = tl;
+    K = N;
+    FF_TL(2 + l);
+  }
+  if (!a.do_head) return;
+  // `in` now holds the last hidden activations [32][HL]
+  switch (K) {
+    case 128: fused_head<128>(a, in, ldin, net, r0, ring); break;
+    case 256: fused_head<256>(a, in, ldin, net, r0, ring); break;
+    case 512: fused_head<512>(a, in, ldin, net, r0, ring); break;
+    default: break;
+  }
+  FF_TL(8);
+}
+
+#ifdef FUSED_TL
+extern "C" int catppo_debug_fused_tl(void* buf) {     // timeline builds only: not part of include/catppo.h
+  unsigned long long* pbuf = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_fftl), &pbuf, sizeof(pbuf)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // ------------------------------------------------------------------------------- minibatch gather
 // grid = (row chunks of one minibatch, minibatches).  Minibatch m = samples inds[m*M .. m*M + M_m) lands in the
 // contiguous slices xmb[m*M ..], act[m*M ..], scal[4*m*M + {0,1,2,3}*M_m ..], adv_part[m][chunk][2].
@@ -1292,6 +1634,35 @@ static int mlp_prologue(catppo_ctx* ctx, const catppo_mlp_shape* shape, int64_t 
 }
 
 namespace {
+// fused_fwd_kernel applies when: fp32 MFMA, every hidden width a multiple of 128 (a wave owns 32 columns of a 256 /
+// 128-column chunk), a head width the head code knows, the two activation tiles + the weight rings fit the LDS, and the
+// batch is in the window where one 32-row workgroup per CU (x 2 networks) beats the layer-wise launches: 2049-4096
+// rows (measured: 4096 rows -0.2 ms per 24-step rollout, 2048 rows equal, below that the workgroup's ~35 us serial
+// time loses to the launch-bound small GEMMs).  CATPPO_FUSED_FWD=0 disables it (A/B), CATPPO_FUSED_FWD_MIN_ROWS /
+// _MAX_ROWS move the window (the tests pin it open to cover small and ragged batches).
+bool fused_fwd_plan(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, int64_t rows, FusedFwdArgs* fa, size_t* lds) {
+  static const int enabled = env_int("CATPPO_FUSED_FWD", 1);
+  static const int max_rows = env_int("CATPPO_FUSED_FWD_MAX_ROWS", 4096);
+  static const int min_rows = env_int("CATPPO_FUSED_FWD_MIN_ROWS", 2049);
+  if (!enabled || rows > max_rows || rows < min_rows || sh->mfma_bf16 != 0) return false;
+  const int nl = sh->n_hidden;
+  const int hl = sh->hidden[nl - 1];
+  if (hl != 128 && hl != 256 && hl != 512) return false;
+  int w0 = L.obs_pad, w1 = 0;
+  for (int l = 0; l < nl; ++l) {
+    if (sh->hidden[l] % 128 != 0) return false;
+    int& dst = (l % 2 == 0) ? w1 : w0;       // layer l writes act1 for even l, act0 for odd l
+    dst = dst > sh->hidden[l] ? dst : sh->hidden[l];
+  }
+  fa->Dp = L.obs_pad, fa->n_hidden = nl;
+  fa->ld0 = w0 + 4, fa->ld1 = w1 + 4;
+  for (int l = 0; l < nl; ++l) fa->hidden[l] = sh->hidden[l];
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l <= nl; ++l) fa->off_w[net][l] = L.off_w[net][l], fa->off_b[net][l] = L.off_b[net][l];
+  *lds = sizeof(float) * ((size_t)kFR * (fa->ld0 + fa->ld1) + kFRing);
+  return *lds <= 160 * 1024;
+}
+
 // rollout policy step shared by catppo_policy_act / _ex / _rng and catppo_value / _ex
 int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
                 const float* eps, const float* given_action, float* action, float* logprob, void* value,
@@ -1303,6 +1674,22 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
   CATPPO_CHECK_ARG(ctx, params && x && value && (critic_only || (action && logprob)));
   CATPPO_CHECK_ARG(ctx, value_dtype == CATPPO_F32 || value_dtype == CATPPO_F16);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    FusedFwdArgs fa{};
+    size_t lds = 0;
+    if (fused_fwd_plan(shape, L, N, &fa, &lds)) {      // small batches: every layer + the head in one launch
+      fa.x = x, fa.params = params, fa.M = N;
+      fa.net0 = 0;
+      fa.logstd = params + L.off_logstd, fa.eps = eps, fa.given = given_action, fa.A = shape->act_dim;
+      fa.action = action, fa.logprob = logprob, fa.value_out = value, fa.value_f16 = (int)(value_dtype == CATPPO_F16);
+      fa.rng_state = rng_state, fa.rng_step = rng_step, fa.eps_out = eps_out, fa.do_head = 1;
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fused_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(fused_fwd_kernel, dim3((unsigned)cdiv64(N, kFR), critic_only ? 1 : 2), dim3(kFT), lds, s, fa);
+      CATPPO_CHECK_LAUNCH(ctx);
+      return CATPPO_OK;
+    }
+  }
   forward_hidden(shape, L, params, x, N, w, 0, critic_only ? 1 : 2, s);
   CATPPO_CHECK_LAUNCH(ctx);
   const int nl = shape->n_hidden, A = critic_only ? 0 : shape->act_dim;

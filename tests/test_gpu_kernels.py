@@ -726,3 +726,62 @@ def test_fused_head_launch_equals_the_two_launch_path(tmp_path, D, A, hidden, Bs
     scale = np.abs(g0).max()
     assert np.abs(g1 - g0).max() <= 2e-5 * scale, (np.abs(g1 - g0).max(), scale)
     np.testing.assert_allclose(outs[0]["diag"][:7], outs[1]["diag"][:7], rtol=2e-5, atol=1e-7)
+
+
+_FUSED_FWD_AB = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.join({root!r}, "tests")); sys.path.insert(0, {root!r})
+sys.path.insert(0, os.path.join({root!r}, "constraints-as-terminations_amd"))
+import streams as S
+import test_gpu_kernels as T
+from cat_envs import native
+nat = native.Native()
+res = {{}}
+for tag, (D, A, hidden, B) in {cases!r}.items():
+    shape = native.shape_of(D, A, hidden)
+    lay = native.layout_of(shape)
+    params = T.flat_params(native, shape, lay, S.agent_weights(9, D, A, hidden))
+    rs = np.random.RandomState(B)
+    x = np.zeros((B, lay.obs_pad), np.float32); x[:, :D] = rs.standard_normal((B, D)) * 1.5
+    eps = rs.standard_normal((B, A)).astype(np.float32)
+    act, lp, val = (torch.empty(B, A, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda"))
+    nat.mlp_reserve(shape, B)
+    nat.policy_act(shape, params, T.dev(x), B, T.dev(eps), act, lp, val)
+    v2 = torch.empty(B, device="cuda")
+    nat.value(shape, params, T.dev(x), B, v2)
+    st = nat.iter_state_new(1234, 3e-4)
+    a3, l3, v3, e3 = torch.empty(B, A, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, A, device="cuda")
+    nat.policy_act_rng(shape, params, T.dev(x), B, st, 5, a3, l3, v3, eps_out=e3)
+    torch.cuda.synchronize()
+    for k, t in (("act", act), ("lp", lp), ("val", val), ("v2", v2), ("a3", a3), ("l3", l3), ("e3", e3)):
+        res[tag + "_" + k] = t.cpu().numpy()
+np.savez({out!r}, **res)
+"""
+
+
+def test_fused_forward_launch_equals_the_layerwise_path(tmp_path):
+    """fused_fwd_kernel (all hidden layers + head of one network per 32-row workgroup) against the layer-wise launches it
+    replaces between 2049 and 4096 rows: two processes (the switches are read once), the window pinned open so that
+    small, ragged and multi-chunk shapes run fused too.  Hidden activations are bit-identical by construction (same
+    contraction order); the head sums in another order: values / means / log-probs agree to 2e-6, Philox noise exactly."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = {"cfg2": (48, 12, (256, 256, 256), 4096), "ref_ragged": (45, 12, (512, 256, 128), 2049),
+             "tiny": (45, 12, (512, 256, 128), 33), "wide_head": (33, 7, (128, 512), 300), "one_row": (48, 12, (256, 128), 1)}
+    outs = []
+    for env_over in (dict(CATPPO_FUSED_FWD="1", CATPPO_FUSED_FWD_MIN_ROWS="1"), dict(CATPPO_FUSED_FWD="0")):
+        out = str(tmp_path / f"ff{len(outs)}.npz")
+        code = _FUSED_FWD_AB.format(root=root, cases=cases, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    f, l = outs
+    for k in f.files:
+        if k.endswith("_e3"):
+            np.testing.assert_array_equal(f[k], l[k], err_msg=k)             # same Philox counters -> same noise
+        else:
+            np.testing.assert_allclose(f[k], l[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(l[k]).max())), err_msg=k)
+    assert np.abs(f["cfg2_act"]).max() > 0 and np.isfinite(f["ref_ragged_lp"]).all()

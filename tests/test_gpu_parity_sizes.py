@@ -264,3 +264,35 @@ def test_cat_reset_c_abi_direct(golden):
             ep_len[torch.from_numpy(ids).cuda()] = 0
     np.testing.assert_array_equal(viol.cpu().numpy(), g["episode_sums"])
     np.testing.assert_array_equal(eprob.cpu().numpy(), g["cstr_mean_values"])
+
+
+def test_set_term_cfg_with_the_same_object_after_an_in_place_edit_acts_on_the_next_step():
+    """``get_term_cfg -> params["limit"] = x -> set_term_cfg(same object)`` used to leave the cached descriptor
+    table untouched for up to 63 steps.  The reference reads ``term_cfg.params`` on every compute()
+    (cat/constraint_manager.py:213-221): the very next compute() must see the new limit."""
+    import smoke_impl
+    from cat_envs.shim import make
+    task, env_cfg, _ = smoke_impl.make_cfgs(64, 8, 256, 1, 1, (256, 256, 256), True, obs_dim=48, seed=4)
+    env = make(task, cfg=env_cfg)
+    env.reset()
+    cm = env.unwrapped.constraint_manager
+    act = torch.zeros(64, 12, device="cuda")
+    for _ in range(3):
+        env.step(act)                                        # the descriptor table is built and cached
+    assert cm._desc_cache is not None
+    name = "joint_torque"
+    off = list(cm.active_terms).index(name)
+    col0 = int(cm._term_off[off])
+    raw0 = cm.cat._p_cstr[:, col0:col0 + 12].clone()         # |tau| - limit of the last step
+    cfg = cm.get_term_cfg(name)
+    old = float(cfg.params["limit"])
+    cfg.params["limit"] = old + 1000.0                       # in-place edit of the SAME object ...
+    cm.set_term_cfg(name, cfg)                               # ... handed back through the manager's API
+    env.step(act)
+    raw1 = cm.cat._p_cstr[:, col0:col0 + 12]
+    assert float(raw1.max()) < -900.0 and float(raw0.max()) > -50.0, (float(raw0.max()), float(raw1.max()))
+    # and without set_term_cfg the 64-step sweep still catches it eventually (documented fallback)
+    cfg.params["limit"] = old
+    for _ in range(70):
+        env.step(act)
+    assert float(cm.cat._p_cstr[:, col0:col0 + 12].max()) > -50.0
