@@ -631,14 +631,35 @@ __device__ __forceinline__ void fused_head(const FusedFwdArgs& a, const float* _
 //  * deeper weight prefetch (three staging register sets, inline-asm loads with exact vmcnt) changed nothing - the
 //    requests are L2 hits that arrive within a slab - and was removed again.
 // One accumulator, contraction order = gemm_body's (slab, 8-k block, lane half, step): bit-identical to the layer-wise path.
+// the first two weight slabs of the NEXT chunk, requested while the current chunk multiplies (a chunk's own prologue is
+// two serial memory round trips, ~1.5 us of a ~12 us layer, with nothing to overlap them inside the chunk)
+struct FusedPre {
+  float4 p0, p1, p2, p3;      // slab 0 rows (lane/4, lane/4 + 16), slab 1 likewise
+  bool valid;                 // wave-uniform
+};
+
 template <int NC>
 __device__ __forceinline__ void fused_chunk(const float* __restrict__ in, const int ldin, float* __restrict__ out,
                                             const int ldout, float* __restrict__ ring, const float* __restrict__ W,
-                                            const float* __restrict__ bias_c, const int c0, const int K) {
+                                            const float* __restrict__ bias_c, const int c0, const int K,
+                                            const float* __restrict__ Wnext, const int Knext, const int NCnext,
+                                            FusedPre& pre) {
   using gemm::f32x16;
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (NC == 128 && wave >= 4) return;                        // wave-uniform: nothing to do in a 128-column chunk
+  const bool want_next = Wnext != nullptr && wave * 32 < NCnext;     // wave-uniform
+  if (NC == 128 && wave >= 4) {                              // wave-uniform: nothing to multiply in a 128-column chunk
+    pre.valid = false;
+    if (want_next) {
+      const float* np_ = Wnext + (int64_t)(wave * 32 + (lane >> 2)) * Knext + 4 * (lane & 3);
+      pre.p0 = *reinterpret_cast<const float4*>(np_);
+      pre.p1 = *reinterpret_cast<const float4*>(np_ + (int64_t)16 * Knext);
+      pre.p2 = *reinterpret_cast<const float4*>(np_ + 16);
+      pre.p3 = *reinterpret_cast<const float4*>(np_ + (int64_t)16 * Knext + 16);
+      pre.valid = true;
+    }
+    return;
+  }
   const int n_slabs = K / 16;
   const float bias = bias_c[wave * 32 + l31];                // requested before the contraction, used after it
   float* const wring = ring + wave * (3 * 32 * kFWS);
@@ -698,12 +719,30 @@ __device__ __forceinline__ void fused_chunk(const float* __restrict__ in, const 
     }                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                    \
   } while (0)
-  // prologue: slabs 0 and 1 into the ring, slab 2 requested
-  FUSED_GL();
-  FUSED_ST(0);
-  FUSED_GL();
-  FUSED_ST(1);
-  FUSED_GL();
+  // prologue: slabs 0 and 1 into the ring (already in registers when the previous chunk requested them), slab 2 requested
+  if (pre.valid) {
+    w0 = pre.p0, w1 = pre.p1;
+    FUSED_ST(0);
+    w0 = pre.p2, w1 = pre.p3;
+    FUSED_ST(1);
+    gp += 32;
+    FUSED_GL();
+  } else {
+    FUSED_GL();
+    FUSED_ST(0);
+    FUSED_GL();
+    FUSED_ST(1);
+    FUSED_GL();
+  }
+  pre.valid = false;
+  if (want_next) {            // lands while this chunk multiplies; stored by the next chunk's prologue
+    const float* np_ = Wnext + (int64_t)(wave * 32 + (lane >> 2)) * Knext + 4 * (lane & 3);
+    pre.p0 = *reinterpret_cast<const float4*>(np_);
+    pre.p1 = *reinterpret_cast<const float4*>(np_ + (int64_t)16 * Knext);
+    pre.p2 = *reinterpret_cast<const float4*>(np_ + 16);
+    pre.p3 = *reinterpret_cast<const float4*>(np_ + (int64_t)16 * Knext + 16);
+    pre.valid = true;
+  }
   a0 = *reinterpret_cast<const float4*>(ap);
   a1 = *reinterpret_cast<const float4*>(ap + 8);
   b0 = *reinterpret_cast<const float4*>(bp);
@@ -767,13 +806,23 @@ __global__ __launch_bounds__(kFT) void fused_fwd_kernel(const FusedFwdArgs a) {
   float* out = act1;
   int ldin = a.ld0, ldout = a.ld1;
   int K = a.Dp;
+  FusedPre pre;
+  pre.valid = false;
   for (int l = 0; l < a.n_hidden; ++l) {
     const int N = a.hidden[l];
     const float* Wl = a.params + a.off_w[net][l];
     const float* bl = a.params + a.off_b[net][l];
     for (int c0 = 0; c0 < N; c0 += 256) {
-      if (N - c0 >= 256) fused_chunk<256>(in, ldin, out, ldout, ring, Wl + (int64_t)c0 * K, bl + c0, c0, K);
-      else fused_chunk<128>(in, ldin, out, ldout, ring, Wl + (int64_t)c0 * K, bl + c0, c0, K);   // 128 columns left
+      // the chunk after this one (same layer or the first of the next layer): its first weight rows, contraction width
+      const float* Wn = nullptr;
+      int Kn = 0, NCn = 0;
+      if (c0 + 256 < N) {
+        Wn = Wl + (int64_t)(c0 + 256) * K, Kn = K, NCn = (N - c0 - 256) >= 256 ? 256 : 128;
+      } else if (l + 1 < a.n_hidden) {
+        Wn = a.params + a.off_w[net][l + 1], Kn = N, NCn = a.hidden[l + 1] >= 256 ? 256 : 128;
+      }
+      if (N - c0 >= 256) fused_chunk<256>(in, ldin, out, ldout, ring, Wl + (int64_t)c0 * K, bl + c0, c0, K, Wn, Kn, NCn, pre);
+      else fused_chunk<128>(in, ldin, out, ldout, ring, Wl + (int64_t)c0 * K, bl + c0, c0, K, Wn, Kn, NCn, pre);   // 128 columns left
     }
     __syncthreads();
     float* hg = a.Hout[blockIdx.y][l];
