@@ -416,7 +416,10 @@ class PPOTrainer:
         if env_g is not None:
             g = env_g == "1"
         if g is None:
-            g = self.M <= 4096
+            # replay pays at every minibatch size: -5 % of an iteration at 2048 rows (launch bound), -1.3 % at 16384
+            # (9.57 -> 9.41 ms of update phase at cfg2, round 3: ~330 launches whose host-side enqueue and inter-launch
+            # gaps the graph removes); round 2 only enabled it up to 4096 rows
+            g = True
         dist_on_torch = parallel.active() and not parallel.native_comm_active()
         # RCCL collectives inside a captured graph are exercised on a world of one here (a one-GPU box); with real
         # peers they stay opt-in (CATPPO_GRAPH_COMM=1) until measured on a multi-GPU node
