@@ -336,6 +336,12 @@ class PPOOracle:
                 eps = None if eps_fn is None else eps_fn(step)
                 given = None if actions_fn is None else actions_fn(step)
                 action, logprob, _, value = self.agent.get_action_and_value(self.next_obs, action=given, eps=eps)
+                if given is not None and eps is not None:
+                    # the action THIS side would have sampled from the same noise (mu + sigma * eps, ppo.py:111): lets a
+                    # caller that replays the device's actions still check the device's sampling arithmetic per step
+                    if not hasattr(self, "own_actions"):
+                        self.own_actions = torch.zeros_like(self.actions)
+                    self.own_actions[step] = self.agent.get_action_and_value(self.next_obs, eps=eps)[0]
             self.values[step], self.actions[step], self.logprobs[step] = q(value.flatten()), action, logprob
             te = time.perf_counter()
             nobs, rew, nd, timeouts, _info = self.env.step(action)

@@ -98,6 +98,8 @@ def compare(trainer, orc, out, tol_scale=1.0, check=True):
     rep["dones"] = err(trainer.dones[1:T].float().cpu(), orc.dones[1:])
     rep["values"] = err(trainer.values.float().cpu(), orc.values)
     rep["logprobs"] = err(trainer.logprobs.cpu(), orc.logprobs)
+    if hasattr(orc, "own_actions"):      # a = mu + sigma * eps of the device vs the oracle's own sample from the same noise
+        rep["actions"] = err(trainer.actions.cpu(), orc.own_actions)
     rep["advantages"] = err(trainer.advantages.float().cpu(), out["advantages"])
     rep["returns"] = err(trainer.returns.float().cpu(), out["returns"])
     flat_ref = torch.cat([p.detach().reshape(-1) for p in orc.agent.parameters()]).numpy()
@@ -110,6 +112,7 @@ def compare(trainer, orc, out, tol_scale=1.0, check=True):
         return rep
     assert rep["rewards"] == 0.0 and rep["dones"] == 0.0, rep          # termination masks are bit-exact
     assert rep["values"] < 2e-5 * tol_scale and rep["logprobs"] < 2e-4 * tol_scale, rep
+    assert rep.get("actions", 0.0) < 2e-5 * tol_scale, rep
     assert rep["advantages"] < 5e-5 * tol_scale and rep["returns"] < 5e-5 * tol_scale, rep
     assert rep["params"] < 2e-4 * tol_scale, rep
     return rep
