@@ -179,6 +179,7 @@ _SIGNATURES = {
     "catppo_broadcast": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     # ---- ABI 0.3
     "catppo_graph_abort": (C.c_int, [_vp, _vp]),
+    "catppo_comm_probe": (C.c_int, []),
     "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "catppo_rlg_episode_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -679,6 +680,11 @@ class Native:
         if rc != 0:
             raise RuntimeError(f"catppo_comm_unique_id failed ({rc}): librccl could not be loaded")
         return bytes(buf)
+
+    def comm_probe(self):
+        """raises unless librccl can be loaded in this process (no communicator, no bootstrap thread is created)"""
+        if self.lib.catppo_comm_probe() != 0:
+            raise RuntimeError("catppo_comm_probe failed: librccl could not be loaded")
 
     def comm_init(self, rank: int, world: int, unique_id: bytes):
         buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)

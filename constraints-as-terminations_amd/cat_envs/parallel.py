@@ -49,8 +49,10 @@ def init_native_comm(nat, group=None) -> bool:
     try:
         if nat.comm_world:
             pre_err = "a communicator already exists on this context"
+        elif r == 0:
+            uid = nat.comm_unique_id()          # dlopens librccl and starts RCCL's bootstrap root: rank 0 only
         else:
-            uid = nat.comm_unique_id()          # dlopens librccl on every rank; only rank 0's id is used
+            nat.comm_probe()                    # dlopens librccl, nothing else
     except (RuntimeError, OSError) as e:
         pre_err = str(e)
     pre = [None] * w

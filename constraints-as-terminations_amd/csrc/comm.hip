@@ -84,6 +84,8 @@ static_assert(sizeof(ncclUniqueId) == CATPPO_UNIQUE_ID_BYTES, "ncclUniqueId is 1
 
 }  // namespace
 
+extern "C" int catppo_comm_probe(void) { return rccl() ? CATPPO_OK : CATPPO_E_COMM; }
+
 extern "C" int catppo_comm_unique_id(uint8_t* out128) {
   if (!out128) return CATPPO_E_ARG;
   RcclApi* r = rccl();

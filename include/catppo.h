@@ -562,6 +562,9 @@ int catppo_graph_abort(catppo_ctx* ctx, void* stream);
  * reduction), :562-564 (KL all-reduce); the CleanRL path of the reference has no collective. */
 enum { CATPPO_SUM = 0, CATPPO_MAX = 1 };
 #define CATPPO_UNIQUE_ID_BYTES 128
+/* can this process use the collectives at all (librccl loadable, every entry point present)?  No communicator, no
+ * bootstrap thread: what every rank checks BEFORE anybody enters the blocking catppo_comm_init. */
+int catppo_comm_probe(void);
 int catppo_comm_unique_id(uint8_t* out128);
 int catppo_comm_init(catppo_ctx* ctx, int rank, int world, const uint8_t* unique_id128);
 int catppo_comm_world(catppo_ctx* ctx);   /* 0 = no communicator */

@@ -150,6 +150,10 @@ def _worker(rank, world, port, out_dir):
                 raise RuntimeError("catppo_comm_unique_id failed (-6): librccl could not be loaded")
             return bytes(128)
 
+        def comm_probe(self):
+            if self.fail_id:
+                raise RuntimeError("catppo_comm_probe failed: librccl could not be loaded")
+
         def comm_init(self, r, w, uid):
             assert len(uid) == 128 and w == world
             self.init_calls += 1
