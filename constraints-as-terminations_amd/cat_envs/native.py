@@ -85,7 +85,7 @@ class RolloutStep(C.Structure):
         ("obs_raw", C.c_void_p), ("obs_ld", C.c_int64),
         ("obs_mean", C.c_void_p), ("obs_var", C.c_void_p), ("obs_count", C.c_void_p), ("obs_eps", C.c_float),
         ("obs_rows_total", C.c_double), ("obs_out", C.c_void_p), ("obs_out_ld", C.c_int64),
-        ("xchg", C.c_void_p)]
+        ("xchg", C.c_void_p), ("xchg_gathered", C.c_void_p), ("xchg_records", C.c_int32)]
 
 
 F32, F16, F64 = 0, 1, 2                 # CATPPO_F32 / _F16 / _F64
@@ -180,6 +180,7 @@ _SIGNATURES = {
     # ---- ABI 0.3
     "catppo_graph_abort": (C.c_int, [_vp, _vp]),
     "catppo_comm_probe": (C.c_int, []),
+    "catppo_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "catppo_rlg_episode_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
@@ -700,6 +701,12 @@ class Native:
     def allreduce(self, t: torch.Tensor, op: int = SUM):
         self._ok(self.lib.catppo_allreduce(self.h, _p(_chk(t, t.dtype, "allreduce operand")), t.numel(), self._dt(t),
                                            int(op), self._stream()))
+
+    def allgather(self, send: torch.Tensor, recv: torch.Tensor):
+        """recv (uint8, world * send.numel() bytes) <- every rank's send (uint8), rank order"""
+        _chk(send, torch.uint8, "allgather send")
+        _chk(recv, torch.uint8, "allgather recv")
+        self._ok(self.lib.catppo_allgather(self.h, _p(send), _p(recv), send.numel(), self._stream()))
 
     def broadcast(self, t: torch.Tensor, root: int = 0):
         self._ok(self.lib.catppo_broadcast(self.h, _p(_chk(t, t.dtype, "broadcast operand")), t.numel(), self._dt(t),

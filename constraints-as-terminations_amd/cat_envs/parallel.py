@@ -160,6 +160,24 @@ def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
                        lambda x: dist.broadcast(x, src=src, group=group))
 
 
+def allgather_bytes_(send: torch.Tensor, recv: torch.Tensor, group=None) -> torch.Tensor:
+    """recv (uint8 [world * n]) <- the uint8 [n] record of every rank, in rank order: ONE collective for a record that
+    mixes reductions (the fused env step's {column maxima: MAX | moment sums: SUM}); the consumer folds the records
+    itself, in rank order, so every rank computes bit-identical results"""
+    if not active(group):
+        recv[:send.numel()].copy_(send)
+        return recv
+    if _native is not None and send.is_cuda and group in (None, dist.group.WORLD):
+        _native.allgather(send, recv)
+    elif _host_staged(send, group):
+        h = torch.empty(recv.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(h, send.detach().cpu(), group=group)
+        recv.copy_(h)
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    return recv
+
+
 def gather_counts(n_local: int, device=None, group=None) -> list:
     """[n of rank 0, n of rank 1, ...] as Python ints (one small SUM all-reduce; world of one: [n_local])"""
     w, r = world_size(group), rank(group)

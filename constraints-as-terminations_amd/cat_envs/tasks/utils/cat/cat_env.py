@@ -321,6 +321,7 @@ class CaTEnv:
             self._xchg = nat.rollout_xchg_new(cm.cat._p_cstr.shape[1], self.obs_dim)
             st.xchg = self._xchg.data_ptr()
             self._xchg_views = nat.rollout_xchg_views(self._xchg, cm.cat._p_cstr.shape[1], self.obs_dim)
+            self._xchg_all = None
             self._rstep_ref = C.byref(st)
         if action.dtype != torch.float32 or not action.is_contiguous():
             action = action.float().contiguous()
@@ -338,10 +339,22 @@ class CaTEnv:
         # divisor was global: the running mean shrank by 1/world per update).
         par = self._parallel
         group, obs_group = cm.dist_group, getattr(sink, "obs_group", None)
-        if group is not None and par.active(group):
-            par.allreduce_max_(self._xchg_views[0], group)    # exact (max is order independent): masks stay bit-exact
-        if obs_group is not None and par.active(obs_group):
-            par.allreduce_sum_(self._xchg_views[1], obs_group)   # fp64 [sum x | sum x^2]
+        g_on = group is not None and par.active(group)
+        o_on = obs_group is not None and par.active(obs_group)
+        if g_on and o_on and group is obs_group:
+            # exact mode: ONE collective per env step - all-gather this rank's record {colmax | sums}; rollout_post folds
+            # the records of all ranks itself (MAX is exact, the sums run in rank order on every rank)
+            if self._xchg_all is None:
+                self._xchg_all = torch.zeros(par.world_size(group) * self._xchg.numel(), dtype=torch.uint8,
+                                             device=self.device)
+                st.xchg_gathered, st.xchg_records = self._xchg_all.data_ptr(), par.world_size(group)
+            par.allgather_bytes_(self._xchg, self._xchg_all, group)
+        else:
+            st.xchg_records = 0
+            if g_on:
+                par.allreduce_max_(self._xchg_views[0], group)    # exact (max is order independent): masks stay bit-exact
+            if o_on:
+                par.allreduce_sum_(self._xchg_views[1], obs_group)   # fp64 [sum x | sum x^2]
         rc = lib.catppo_rollout_post(h, self._rstep_ref, stream)
         if rc:
             nat._ok(rc)

@@ -22,6 +22,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   char why[256] = {0};
 };
@@ -52,8 +53,9 @@ RcclApi* rccl() {
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
   api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.Broadcast) {
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.Broadcast || !api.AllGather) {
     snprintf(api.why, sizeof(api.why), "librccl is missing an entry point");
     dlclose(h);
     return nullptr;
@@ -153,5 +155,16 @@ extern "C" int catppo_broadcast(catppo_ctx* ctx, void* buf, int64_t count, int d
   const ncclResult_t rc = r->Broadcast(buf, buf, (size_t)count, dt, root, static_cast<ncclComm_t>(ctx->comm),
                                        static_cast<hipStream_t>(stream));
   if (rc != ncclSuccess) return comm_fail(ctx, r, "ncclBroadcast", rc);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_allgather(catppo_ctx* ctx, const void* send, void* recv, int64_t bytes, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, send != nullptr && recv != nullptr && bytes >= 1);
+  if (!ctx->comm) return catppo_fail(ctx, CATPPO_E_COMM, "catppo_allgather: no communicator (catppo_comm_init)");
+  RcclApi* r = rccl();
+  const ncclResult_t rc = r->AllGather(send, recv, (size_t)bytes, ncclUint8, static_cast<ncclComm_t>(ctx->comm),
+                                       static_cast<hipStream_t>(stream));
+  if (rc != ncclSuccess) return comm_fail(ctx, r, "ncclAllGather", rc);
   return CATPPO_OK;
 }

@@ -311,6 +311,8 @@ struct PostArgs {
   int64_t obs_out_ld;
   const float* x_colmax;
   const double* x_sums;
+  int x_records;          // > 1: x_colmax / x_sums point at record 0 of `x_records` gathered records, x_stride bytes apart
+  int64_t x_stride;
   double* reset_part;     // [grid][n_terms][2]
   double* reset_cnt;      // [grid]
   unsigned int* ticket;
@@ -342,7 +344,9 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
   for (int c = threadIdx.x; c < K; c += kThreads) {
     int t = 0;
     while (t + 1 < nt && c >= s_off[t + 1]) ++t;
-    const float m = a.x_colmax[c];
+    float m = a.x_colmax[c];
+    for (int w = 1; w < a.x_records; ++w)     // gathered records of the other ranks: MAX is exact and order independent
+      m = nanmax(m, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_colmax) + w * a.x_stride)[c]);
     float r;
     if (a.first_call) {
       r = m;
@@ -361,8 +365,13 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const float tot = cnt + nf;
     if (threadIdx.x == 0) s_tot = tot;
     for (int c = threadIdx.x; c < D; c += kThreads) {
-      const double m = a.x_sums[c] / a.obs_n;
-      double v = a.x_sums[D + c] / a.obs_n - m * m;
+      double sx = a.x_sums[c], sxx = a.x_sums[D + c];
+      for (int w = 1; w < a.x_records; ++w) {   // rank order: the same sums on every rank
+        const double* xs = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x_sums) + w * a.x_stride);
+        sx += xs[c], sxx += xs[D + c];
+      }
+      const double m = sx / a.obs_n;
+      double v = sxx / a.obs_n - m * m;
       if (v < 0.0) v = 0.0;
       const float bm = (float)m, bv = (float)v;
       const float mean = a.obs_mean[c];
@@ -634,8 +643,11 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   p.obs_mean = a->obs_mean, p.obs_var = a->obs_var, p.obs_count = a->obs_count, p.obs_eps = a->obs_eps;
   p.obs_n = a->obs_rows_total;
   p.obs_out = a->obs_out, p.obs_out_ld = a->obs_out_ld;
-  p.x_colmax = static_cast<const float*>(a->xchg);
-  p.x_sums = reinterpret_cast<const double*>(static_cast<const char*>(a->xchg) + xchg_sum_offset(K));
+  const void* xbase = (a->xchg_records > 1 && a->xchg_gathered != nullptr) ? a->xchg_gathered : a->xchg;
+  p.x_colmax = static_cast<const float*>(xbase);
+  p.x_sums = reinterpret_cast<const double*>(static_cast<const char*>(xbase) + xchg_sum_offset(K));
+  p.x_records = (a->xchg_records > 1 && a->xchg_gathered != nullptr) ? a->xchg_records : 1;
+  p.x_stride = (int64_t)(xchg_sum_offset(K) + (uint64_t)2 * (a->D > 0 ? a->D : 1) * sizeof(double));
   p.reset_part = rpart, p.reset_cnt = rcnt;
   p.ticket = ctx->tickets + catppo_ctx::kTicketPost;
   if (lds > 64 * 1024)

@@ -505,6 +505,12 @@ typedef struct catppo_rollout_step {
   float* obs_out; int64_t obs_out_ld;
   /* exchange buffer, device: K floats (as doubles' storage is separate) - see catppo_rollout_xchg_bytes */
   void* xchg;
+  /* env-sharded, ONE collective per env step (ABI 0.3): catppo_rollout_pre writes this rank's record into `xchg`; the
+   * caller all-gathers the records of all ranks (catppo_allgather, catppo_rollout_xchg_bytes each, rank order) into
+   * `xchg_gathered`, and catppo_rollout_post folds them itself - column maxima by MAX (exact), moment sums in rank order
+   * (identical on every rank).  xchg_records = number of records (0 / 1: read `xchg`, e.g. after MAX / SUM all-reduces). */
+  const void* xchg_gathered;
+  int32_t xchg_records;
 } catppo_rollout_step;
 uint64_t catppo_rollout_xchg_bytes(int K, int D);
 uint64_t catppo_rollout_step_sizeof(void);   /* sizeof(catppo_rollout_step): lets a binding check its struct layout */
@@ -571,6 +577,8 @@ int catppo_comm_world(catppo_ctx* ctx);   /* 0 = no communicator */
 int catppo_comm_destroy(catppo_ctx* ctx);
 int catppo_allreduce(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int op, void* stream);
 int catppo_broadcast(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int root, void* stream);
+/* recv[rank * bytes ...] = send of that rank, for every rank (ncclAllGather of raw bytes; send != recv) */
+int catppo_allgather(catppo_ctx* ctx, const void* send, void* recv, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -181,6 +181,12 @@ def _worker(rank, world, port, out_dir):
     parallel.allreduce_sum_(chk)                   # the fallback transport still works
     assert float(chk) == world
 
+    # ---- 3b. the fused env step's ONE exchange per step: every rank's byte record, in rank order, on every rank
+    rec = torch.full((24,), rank + 1, dtype=torch.uint8)
+    allr = torch.zeros(24 * world, dtype=torch.uint8)
+    parallel.allgather_bytes_(rec, allr)
+    assert allr.view(world, 24).eq(torch.arange(1, world + 1, dtype=torch.uint8)[:, None]).all()
+
     # ---- 4. broadcast of the flat parameters from rank 0
     flat = torch.full((10,), float(rank))
     parallel.broadcast_(flat, src=0)
