@@ -68,19 +68,22 @@ __global__ __launch_bounds__(256) void rlg_episode_step_kernel(const float* __re
   __syncthreads();
   if (threadIdx.x < NS) {
     const int q = threadIdx.x;
-    part[(int64_t)blockIdx.x * NS + q] = (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]);
+    __hip_atomic_store(part + (int64_t)blockIdx.x * NS + q, (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  // last workgroup to arrive folds the partials in block order (result independent of arrival order)
-  __threadfence();
+  // last workgroup to arrive folds the partials in block order (result independent of arrival order).  No device-scope
+  // fences (an L2 write-back / invalidate per workgroup on gfx950, see rollout.hip): the partial rows are device-scope
+  // atomic stores, complete before the arrive, and read back with device-scope atomic loads.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   if (threadIdx.x < NS) {
     const int q = threadIdx.x;
     double s = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b) s += __builtin_nontemporal_load(part + (int64_t)b * NS + q);
+    for (unsigned b = 0; b < gridDim.x; ++b)
+      s += __hip_atomic_load(part + (int64_t)b * NS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sm[0][q] = s;
   }
   __syncthreads();

@@ -73,10 +73,37 @@ struct PreArgs {
 constexpr int kFoldGroup = 32;    // workgroups per first-level fold
 constexpr int kMaxPreBlocks = 1024;
 
+// Data that crosses workgroups inside a launch (partial rows -> the workgroup that folds them).  Device-scope FENCES are
+// what this must not be built on: on gfx950 a __threadfence() is an L2 write-back / invalidate of the whole XCD slice and
+// measured 10-25 us per launch when every workgroup executes one (profiles/r3_fna_variants.txt).  The partial rows are
+// instead written with device-scope atomic stores and read with device-scope atomic loads (both go to the coherence
+// point by themselves, nothing else needs flushing), ordered by waiting for the stores' completion (s_waitcnt vmcnt(0))
+// before the arrive.  ROLLOUT_FENCES=1 rebuilds the fence version (A/B).
+#ifndef ROLLOUT_FENCES
+#define ROLLOUT_FENCES 0
+#endif
+template <typename T>
+__device__ __forceinline__ void xwg_store(T* p, T v) {
+#if ROLLOUT_FENCES
+  *p = v;
+#else
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T xwg_load(const T* p) {
+#if ROLLOUT_FENCES
+  return __builtin_nontemporal_load(p);
+#else
+  return __hip_atomic_load(const_cast<T*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 __device__ __forceinline__ bool last_block_arrives(unsigned int* ticket, unsigned int expected) {
-  // classic "last block folds" hand-shake: make this workgroup's global writes visible device wide, take a ticket,
-  // and if it is the last one make every other workgroup's writes visible to this one
+  // "last workgroup folds" hand-shake: every xwg_store of this workgroup has completed, take a ticket; the last one
+  // reads the other workgroups' rows with xwg_load
   __shared__ int s_last;
+#if ROLLOUT_FENCES
   __syncthreads();          // every store of the workgroup has left the CU (write-through L1) ...
   if (threadIdx.x == 0) {
     __threadfence();        // ... release at device scope: L2 write-back, visible to the other XCDs
@@ -88,6 +115,17 @@ __device__ __forceinline__ bool last_block_arrives(unsigned int* ticket, unsigne
   const bool last = s_last != 0;
   if (last) __threadfence();   // acquire: drop stale cache lines before reading the other workgroups' partials
   return last;
+#else
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's device-scope stores have completed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(ticket, 1u);
+    s_last = (t == expected - 1) ? 1 : 0;
+    if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch (stream ordered)
+  }
+  __syncthreads();
+  return s_last != 0;
+#endif
 }
 
 // Block-wide fold of partial[nrows][ncols] over the rows.  Thread (c, g): column c, row group g of G = 256 / ncols;
@@ -107,13 +145,13 @@ __device__ __forceinline__ void block_fold(const T* __restrict__ partial, int nr
       T a0 = init, a1 = init, a2 = init, a3 = init;
       int b = g;
       for (; b + 3 * G < nrows; b += 4 * G) {
-        const T x0 = __builtin_nontemporal_load(partial + (int64_t)b * ncols + c);
-        const T x1 = __builtin_nontemporal_load(partial + (int64_t)(b + G) * ncols + c);
-        const T x2 = __builtin_nontemporal_load(partial + (int64_t)(b + 2 * G) * ncols + c);
-        const T x3 = __builtin_nontemporal_load(partial + (int64_t)(b + 3 * G) * ncols + c);
+        const T x0 = xwg_load(partial + (int64_t)b * ncols + c);
+        const T x1 = xwg_load(partial + (int64_t)(b + G) * ncols + c);
+        const T x2 = xwg_load(partial + (int64_t)(b + 2 * G) * ncols + c);
+        const T x3 = xwg_load(partial + (int64_t)(b + 3 * G) * ncols + c);
         a0 = op(a0, x0), a1 = op(a1, x1), a2 = op(a2, x2), a3 = op(a3, x3);
       }
-      for (; b < nrows; b += G) a0 = op(a0, __builtin_nontemporal_load(partial + (int64_t)b * ncols + c));
+      for (; b < nrows; b += G) a0 = op(a0, xwg_load(partial + (int64_t)b * ncols + c));
       acc = op(op(a0, a1), op(a2, a3));
     }
     lds[threadIdx.x] = acc;
@@ -222,7 +260,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
     __syncthreads();
   }
   RL_TL(0, 2);
-  for (int c = threadIdx.x; c < K; c += kThreads) a.colmax_partial[(int64_t)blockIdx.x * K + c] = cmax[c];
+  for (int c = threadIdx.x; c < K; c += kThreads) xwg_store(a.colmax_partial + (int64_t)blockIdx.x * K + c, cmax[c]);
   if (a.obs_raw != nullptr) {
     // combine the row groups of the block in ascending g (fixed order), one partial row per block
 #pragma unroll
@@ -235,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
         if (og == 0 && c < D && (q == 0 || D > kThreads)) {
           double t = fold_lds[oc];
           for (int gg = 1; gg < OG; ++gg) t += fold_lds[gg * Dc + oc];
-          a.osum_partial[(int64_t)blockIdx.x * 2 * D + pass * D + c] = t;
+          xwg_store(a.osum_partial + (int64_t)blockIdx.x * 2 * D + pass * D + c, t);
         }
       }
     }
@@ -252,10 +290,10 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   if (!last1) return;
   block_fold<float>(a.colmax_partial + (int64_t)g0 * K, g_rows, K, -__builtin_inff(),
                     [](float x, float y) { return nanmax(x, y); }, reinterpret_cast<float*>(fold_lds),
-                    [&](int c, float m) { a.colmax_group[(int64_t)grp * K + c] = m; });
+                    [&](int c, float m) { xwg_store(a.colmax_group + (int64_t)grp * K + c, m); });
   if (a.obs_raw != nullptr)
     block_fold<double>(a.osum_partial + (int64_t)g0 * 2 * D, g_rows, 2 * D, 0.0, [](double x, double y) { return x + y; },
-                       fold_lds, [&](int c, double v) { a.osum_group[(int64_t)grp * 2 * D + c] = v; });
+                       fold_lds, [&](int c, double v) { xwg_store(a.osum_group + (int64_t)grp * 2 * D + c, v); });
   RL_TL(0, 5);
   const bool last2 = last_block_arrives(a.ticket, (unsigned)n_grp);
   RL_TL(0, 6);
@@ -446,8 +484,8 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const int t = threadIdx.x;
     double sa = 0.0, sb = 0.0;
     for (int e = 0; e < kPostRows; ++e) sa += red[t * kPostRows + e], sb += red[nt * kPostRows + t * kPostRows + e];
-    a.reset_part[((int64_t)blockIdx.x * nt + t) * 2] = sa;
-    a.reset_part[((int64_t)blockIdx.x * nt + t) * 2 + 1] = sb;
+    xwg_store(a.reset_part + ((int64_t)blockIdx.x * nt + t) * 2, sa);
+    xwg_store(a.reset_part + ((int64_t)blockIdx.x * nt + t) * 2 + 1, sb);
   }
   // ---- per env: probability, reward, dones (cat_env.py:102-107,118-121), rollout rows, reset bookkeeping
   if (threadIdx.x < rows) {
@@ -463,7 +501,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const bool rs = a.reset[i] != 0;
     {   // envs of this tile that reset: rows <= 32 live in the first half of wave 0
       const unsigned long long mask = __ballot(rs);
-      if (threadIdx.x == 0) a.reset_cnt[blockIdx.x] = (double)__popcll(mask);
+      if (threadIdx.x == 0) xwg_store(a.reset_cnt + blockIdx.x, (double)__popcll(mask));
     }
     const float dn = rs ? 1.0f : p;
     if (a.dones) a.dones[i] = dn;
