@@ -128,30 +128,59 @@ __device__ __forceinline__ bool last_block_arrives(unsigned int* ticket, unsigne
 #endif
 }
 
-// Block-wide fold of partial[nrows][ncols] over the rows.  Thread (c, g): column c, row group g of G = 256 / ncols;
-// a thread walks rows g, g+G, ... with four independent accumulators (the loads of a step do not depend on each other:
-// several are in flight), the G group results are combined through LDS in ascending g.  The order of the combination
-// depends only on (nrows, ncols) => deterministic.  finish(c, value) is called by one thread per column.
+// Block-wide fold of partial[nrows][ncols] over the rows.  Thread (c, g): column c, row group g of G <= 256 / ncols
+// groups; a thread walks rows g, g+G, ... with four accumulators (row j of the thread goes to accumulator j % 4, a tail of
+// fewer than four rows to accumulator 0), the G group results are combined through LDS in ascending g.  The order of the
+// combination depends only on (nrows, ncols) => deterministic.  Up to 16 rows per thread (every fold of the rollout
+// step) are ALL requested before the first is used: the rows come from the coherence point (xwg_load), a round trip of
+// ~2 us each, and a fold used to pay three or four of them in sequence.  finish(c, value): one thread per column.
 template <typename T, typename Op, typename Fin>
 __device__ __forceinline__ void block_fold(const T* __restrict__ partial, int nrows, int ncols, T init, Op op, T* lds,
                                            Fin finish) {
+  constexpr int kInFlight = 16;
   const int Wc = ncols < kThreads ? ncols : kThreads;
-  const int G = kThreads / Wc;
+  // narrow folds (one column: 256 candidate groups) keep 16 groups unless that leaves a thread more than 16 rows:
+  // the LDS combination below is serial in G
+  const int Gmax = kThreads / Wc;
+  const int Gneed = (nrows + kInFlight - 1) / kInFlight;
+  const int G = Gmax <= 16 ? Gmax : (Gneed > 16 ? (Gneed < Gmax ? Gneed : Gmax) : 16);
   const int c0 = threadIdx.x % Wc, g = threadIdx.x / Wc;
   for (int cb = 0; cb < ncols; cb += Wc) {
     const int c = cb + c0;
     T acc = init;
     if (g < G && c < ncols) {
       T a0 = init, a1 = init, a2 = init, a3 = init;
-      int b = g;
-      for (; b + 3 * G < nrows; b += 4 * G) {
-        const T x0 = xwg_load(partial + (int64_t)b * ncols + c);
-        const T x1 = xwg_load(partial + (int64_t)(b + G) * ncols + c);
-        const T x2 = xwg_load(partial + (int64_t)(b + 2 * G) * ncols + c);
-        const T x3 = xwg_load(partial + (int64_t)(b + 3 * G) * ncols + c);
-        a0 = op(a0, x0), a1 = op(a1, x1), a2 = op(a2, x2), a3 = op(a3, x3);
+      const int n_t = g < nrows ? (nrows - g + G - 1) / G : 0;       // rows of this thread
+      if (n_t <= kInFlight) {
+        T x[kInFlight];
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+          const int bb = g + j * G;
+          x[j] = xwg_load(partial + (int64_t)(bb < nrows ? bb : (nrows - 1)) * ncols + c);   // past the end: re-read, unused
+        }
+        const int n4 = n_t / 4 * 4;
+#pragma unroll
+        for (int j = 0; j < kInFlight; ++j) {
+          if (j < n4) {
+            if (j % 4 == 0) a0 = op(a0, x[j]);
+            if (j % 4 == 1) a1 = op(a1, x[j]);
+            if (j % 4 == 2) a2 = op(a2, x[j]);
+            if (j % 4 == 3) a3 = op(a3, x[j]);
+          } else if (j < n_t) {
+            a0 = op(a0, x[j]);
+          }
+        }
+      } else {
+        int b = g;
+        for (; b + 3 * G < nrows; b += 4 * G) {
+          const T x0 = xwg_load(partial + (int64_t)b * ncols + c);
+          const T x1 = xwg_load(partial + (int64_t)(b + G) * ncols + c);
+          const T x2 = xwg_load(partial + (int64_t)(b + 2 * G) * ncols + c);
+          const T x3 = xwg_load(partial + (int64_t)(b + 3 * G) * ncols + c);
+          a0 = op(a0, x0), a1 = op(a1, x1), a2 = op(a2, x2), a3 = op(a3, x3);
+        }
+        for (; b < nrows; b += G) a0 = op(a0, xwg_load(partial + (int64_t)b * ncols + c));
       }
-      for (; b < nrows; b += G) a0 = op(a0, xwg_load(partial + (int64_t)b * ncols + c));
       acc = op(op(a0, a1), op(a2, a3));
     }
     lds[threadIdx.x] = acc;
