@@ -9,4 +9,5 @@ registry replacing ``gym.register`` / ``gym.make`` / ``load_cfg_from_registry``.
 from .configclass import MISSING, configclass  # noqa: F401
 from .managers import (CurriculumTermCfg, ManagerBase, ManagerTermBase, ManagerTermBaseCfg,  # noqa: F401
                        SceneEntityCfg)
-from .registry import load_cfg_from_registry, make, register, registry  # noqa: F401
+from .registry import (apply_overrides, hydra_task_config, load_cfg_from_registry, make, register,  # noqa: F401
+                       registry)

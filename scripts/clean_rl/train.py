@@ -7,9 +7,10 @@ Same command line as the reference (scripts/clean_rl/train.py):
 Isaac Sim cannot run on an AMD box, so the task registry and config classes of ``cat_envs.shim``
 stand in for gymnasium / hydra and the env is driven by the device-resident synthetic Solo12 stream;
 only AppLauncher's argument definitions are picked up when IsaacLab happens to be importable.
-``key=value`` overrides after the flags are applied to the env / agent configs
-(``env.scene.num_envs=1024 agent.minibatch_size=8192``) - the same dotted syntax as the reference's
-hydra overrides, resolved here without hydra.
+``key=value`` arguments (``env.scene.num_envs=1024 agent.minibatch_size=8192``) are the reference's hydra overrides:
+like there (train.py:57-61,92) they are moved to ``sys.argv`` after argparse and applied by the ``hydra_task_config``
+decorator BEFORE ``main``'s body, so the explicit flags (--num_envs, --seed, --num_iterations, --device) win over them.
+``cat_envs.shim.hydra_task_config`` resolves them without hydra; IsaacLab's own decorator is used when it is importable.
 """
 import argparse
 import os
@@ -46,19 +47,9 @@ def build_parser():
 
 
 def apply_overrides(cfgs: dict, overrides):
-    """``env.a.b=value`` / ``agent.x=value`` (hydra-style dotted overrides)"""
-    import ast
-    for ov in overrides:
-        key, _, raw = ov.partition("=")
-        root, *path = key.split(".")
-        obj = cfgs[root]
-        for name in path[:-1]:
-            obj = getattr(obj, name)
-        try:
-            value = ast.literal_eval(raw)
-        except (ValueError, SyntaxError):
-            value = raw
-        setattr(obj, path[-1], value)
+    """hydra-style dotted overrides (kept as a module-level name for callers of round 1/2)"""
+    from cat_envs.shim import apply_overrides as _apply
+    _apply(cfgs, overrides)
 
 
 def dump_cfg(path, cfg):
@@ -73,14 +64,20 @@ def dump_cfg(path, cfg):
 
 
 def main(argv=None):
-    args_cli, overrides = build_parser().parse_known_args(argv)
+    args_cli, hydra_args = build_parser().parse_known_args(argv)
     if args_cli.video:
         args_cli.enable_cameras = True
+    # clear out sys.argv for the override resolver, like the reference does for Hydra (train.py:57-58)
+    sys.argv = [sys.argv[0]] + hydra_args
     import torch
 
     import cat_envs.tasks  # noqa: F401  registers the tasks
-    from cat_envs.shim import load_cfg_from_registry, make
+    from cat_envs.shim import make
     from cat_envs.tasks.utils.cleanrl.ppo import PPO
+    try:
+        from isaaclab_tasks.utils.hydra import hydra_task_config
+    except ImportError:
+        from cat_envs.shim import hydra_task_config
 
     if torch.distributed.is_available() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -89,34 +86,36 @@ def main(argv=None):
         if args_cli.device is None:
             args_cli.device = f"cuda:{local}"
 
-    env_cfg = load_cfg_from_registry(args_cli.task, "env_cfg_entry_point")
-    agent_cfg = load_cfg_from_registry(args_cli.task, "clean_rl_cfg_entry_point")
-    agent_cfg = cli_args.update_clean_rl_cfg(agent_cfg, args_cli)
-    env_cfg.scene.num_envs = args_cli.num_envs if args_cli.num_envs is not None else env_cfg.scene.num_envs
-    agent_cfg.num_iterations = (args_cli.num_iterations if args_cli.num_iterations is not None
-                                else agent_cfg.num_iterations)
-    # env-sharded runs (torchrun): every rank owns its own block of --num_envs environments with its own stream
-    # (seed + rank, like the reference's distributed front-ends: scripts/rl_games/train.py:100-107), so the
-    # all-reduces combine distinct shards; rank 0 alone writes the run directory
-    rank = int(os.environ.get("RANK", "0")) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0
-    env_cfg.seed = agent_cfg.seed + rank
-    env_cfg.sim.device = args_cli.device if args_cli.device is not None else env_cfg.sim.device
-    apply_overrides({"env": env_cfg, "agent": agent_cfg}, [o for o in overrides if "=" in o])
+    @hydra_task_config(args_cli.task, "clean_rl_cfg_entry_point")
+    def run(env_cfg, agent_cfg):
+        # override configurations with the non-hydra CLI arguments (reference train.py:98-107)
+        agent_cfg = cli_args.update_clean_rl_cfg(agent_cfg, args_cli)
+        env_cfg.scene.num_envs = args_cli.num_envs if args_cli.num_envs is not None else env_cfg.scene.num_envs
+        agent_cfg.num_iterations = (args_cli.num_iterations if args_cli.num_iterations is not None
+                                    else agent_cfg.num_iterations)
+        # env-sharded runs (torchrun): every rank owns its own block of --num_envs environments with its own stream
+        # (seed + rank, like the reference's distributed front-ends: scripts/rl_games/train.py:100-107), so the
+        # all-reduces combine distinct shards; rank 0 alone writes the run directory
+        rank = int(os.environ.get("RANK", "0")) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0
+        env_cfg.seed = agent_cfg.seed + rank
+        env_cfg.sim.device = args_cli.device if args_cli.device is not None else env_cfg.sim.device
 
-    log_root_path = os.path.abspath(os.path.join("logs", "clean_rl", agent_cfg.experiment_name))
-    print(f"[INFO] Logging experiment in directory: {log_root_path}")
-    log_dir = os.path.join(log_root_path, datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
-    if rank == 0:
-        dump_cfg(os.path.join(log_dir, "params", "env.yaml"), env_cfg)
-        dump_cfg(os.path.join(log_dir, "params", "agent.yaml"), agent_cfg)
-        dump_cfg(os.path.join(log_dir, "params", "env.pkl"), env_cfg)
-        dump_cfg(os.path.join(log_dir, "params", "agent.pkl"), agent_cfg)
+        log_root_path = os.path.abspath(os.path.join("logs", "clean_rl", agent_cfg.experiment_name))
+        print(f"[INFO] Logging experiment in directory: {log_root_path}")
+        log_dir = os.path.join(log_root_path, datetime.now().strftime("%Y-%m-%d_%H-%M-%S"))
+        if rank == 0:
+            dump_cfg(os.path.join(log_dir, "params", "env.yaml"), env_cfg)
+            dump_cfg(os.path.join(log_dir, "params", "agent.yaml"), agent_cfg)
+            dump_cfg(os.path.join(log_dir, "params", "env.pkl"), env_cfg)
+            dump_cfg(os.path.join(log_dir, "params", "agent.pkl"), agent_cfg)
 
-    env = make(args_cli.task, cfg=env_cfg, render_mode="rgb_array" if args_cli.video else None)
-    if args_cli.video:
-        print("[WARN] video recording needs Isaac Sim rendering; ignored with the synthetic simulator")
-    PPO(env, agent_cfg, log_dir)
-    env.close()
+        env = make(args_cli.task, cfg=env_cfg, render_mode="rgb_array" if args_cli.video else None)
+        if args_cli.video:
+            print("[WARN] video recording needs Isaac Sim rendering; ignored with the synthetic simulator")
+        PPO(env, agent_cfg, log_dir)
+        env.close()
+
+    run()
 
 
 if __name__ == "__main__":

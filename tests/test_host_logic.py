@@ -134,6 +134,28 @@ def test_cli_surface(tmp_path):
     assert (cfg.seed, cfg.load_run, cfg.load_checkpoint, cfg.logger) == (7, "r", "c.pt", "tensorboard")
     train.apply_overrides({"agent": cfg}, rest)
     assert cfg.minibatch_size == 512
+    # the reference's precedence (train.py:57-61,92-107): the key=value overrides are resolved by the hydra_task_config
+    # decorator BEFORE main's body, so an explicit flag wins over an override of the same field; a typo is an error
+    from cat_envs.shim import hydra_task_config
+    argv0 = sys.argv
+    try:
+        sys.argv = ["train.py", "env.scene.num_envs=128", "agent.hidden=[64,64]", "agent.learning_rate=1e-3"]
+
+        @hydra_task_config("Isaac-Velocity-CaT-Flat-Solo12-v0", "clean_rl_cfg_entry_point")
+        def body(env_cfg, agent_cfg, flag_num_envs):
+            seen = (env_cfg.scene.num_envs, list(agent_cfg.hidden), agent_cfg.learning_rate)
+            env_cfg.scene.num_envs = flag_num_envs if flag_num_envs is not None else env_cfg.scene.num_envs
+            return seen, env_cfg.scene.num_envs
+        assert body(64) == ((128, [64, 64], 1e-3), 64)
+        assert body(None) == ((128, [64, 64], 1e-3), 128)
+        sys.argv = ["train.py", "agent.minibatch_sise=512"]
+        with pytest.raises(AttributeError, match="minibatch_sise"):
+            body(None)
+        sys.argv = ["train.py", "agnt.minibatch_size=512"]
+        with pytest.raises(KeyError, match="agnt"):
+            body(None)
+    finally:
+        sys.argv = argv0
     # checkpoint discovery: latest run, highest iteration (reference naming model_<it>.pt)
     for run, files in (("2026-01-01_00-00-00", ["model_49.pt", "model_99.pt"]), ("2026-02-01_00-00-00", ["model_49.pt", "model_149.pt", "model_99.pt"])):
         os.makedirs(tmp_path / run)
