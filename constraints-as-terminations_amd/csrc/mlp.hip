@@ -1557,16 +1557,62 @@ struct SegTable {
   Seg s[kMaxSegs];
 };
 
-// block = EL elements x G part-groups (EL*G = 256).  Thread (e,g) adds parts g, g+G, ... in order, the G
-// group sums are then combined in LDS in fixed order => deterministic, and at most n_parts/G
-// dependent adds per thread with the loads issued ahead (unrolled).
+// block = EL lanes x G part-groups (EL*G = 256).  Thread (e,g) adds parts g, g+G, ... in order, the G group sums are
+// then combined in LDS in fixed order => deterministic.  Aligned segments (every weight / bias partial): a lane owns FOUR
+// consecutive elements (16-byte loads) and its parts are requested in batches of four or eight that are always full -
+// a batch past the last part re-reads the last part and adds 0 - so the loads of a batch are in flight together
+// whatever the split count (the unrolled loop of rounds 1-2 fell into its serial remainder for the 2-4 parts per thread
+// of a small minibatch).  The order of the additions per element is unchanged: results are bit-identical.
+template <int NB>
+__device__ __forceinline__ float4 seg_sum4(const float* __restrict__ src, int64_t stride, int g, int G, int last) {
+  float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  for (int q0 = g; q0 <= last; q0 += NB * G) {
+    float4 x[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int q = q0 + j * G;
+      x[j] = *reinterpret_cast<const float4*>(src + (int64_t)(q < last ? q : last) * stride);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const bool on = q0 + j * G <= last;
+      a.x += on ? x[j].x : 0.0f, a.y += on ? x[j].y : 0.0f, a.z += on ? x[j].z : 0.0f, a.w += on ? x[j].w : 0.0f;
+    }
+  }
+  return a;
+}
+
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
-  __shared__ float sm[256];
+  __shared__ __attribute__((aligned(16))) float sm[1024];
   const Seg sg = t.s[blockIdx.y];
-  // few wide partials (split-K): 4 part groups x 64 elements (256-B rows); many narrow ones (head): 16 x 16
+  // few wide partials (split-K): 4 part groups x 64 lanes; many narrow ones (head): 16 x 16
   const int G = sg.n_parts >= 128 ? 16 : 4;
   const int EL = 256 / G;
   const int el = threadIdx.x % EL, g = threadIdx.x / EL;
+  const bool vec = sg.mode == 0 && (reinterpret_cast<uintptr_t>(sg.src) & 15) == 0 && sg.stride % 4 == 0 &&
+                   sg.count % 4 == 0 && (reinterpret_cast<uintptr_t>(sg.dst) & 15) == 0;
+  if (vec) {
+    const int last = sg.n_parts - 1;
+    const bool few = (sg.n_parts + G - 1) / G <= 4;         // parts per thread
+    float4* sm4 = reinterpret_cast<float4*>(sm);
+    for (int64_t e0 = (int64_t)blockIdx.x * EL * 4; e0 < sg.count; e0 += (int64_t)gridDim.x * EL * 4) {
+      const int64_t e = e0 + el * 4;
+      float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (e < sg.count && g <= last) a = few ? seg_sum4<4>(sg.src + e, sg.stride, g, G, last)
+                                              : seg_sum4<8>(sg.src + e, sg.stride, g, G, last);
+      sm4[threadIdx.x] = a;
+      __syncthreads();
+      if (g == 0 && e < sg.count) {
+        for (int gg = 1; gg < G; ++gg) {
+          const float4 y = sm4[gg * EL + el];
+          a.x += y.x, a.y += y.y, a.z += y.z, a.w += y.w;
+        }
+        *reinterpret_cast<float4*>(sg.dst + e) = a;
+      }
+      __syncthreads();
+    }
+    return;
+  }
   for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < sg.count; e0 += (int64_t)gridDim.x * EL) {
     const int64_t e = e0 + el;
     float a = 0.0f;
