@@ -51,7 +51,8 @@ class TermDesc(C.Structure):
 class IterState(C.Structure):
     """catppo_iter_state (device resident; this mirror is only used for its size and for read-backs in tests)"""
     _fields_ = [("seed", C.c_uint64), ("iteration", C.c_int64), ("adam_step", C.c_int64), ("lr", C.c_double),
-                ("kl_mark", C.c_double), ("n_mark", C.c_double), ("last_kl", C.c_double), ("reserved", C.c_int64)]
+                ("kl_mark", C.c_double), ("n_mark", C.c_double), ("last_kl", C.c_double), ("adam_step_size", C.c_float),
+                ("adam_bc2_sqrt", C.c_float)]
 
 
 RLG_MAX_VALUE_SIZE = 4

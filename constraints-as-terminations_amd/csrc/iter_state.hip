@@ -17,7 +17,7 @@ __global__ void iter_init_kernel(catppo_iter_state* st, uint64_t seed, double lr
   st->kl_mark = 0.0;
   st->n_mark = 0.0;
   st->last_kl = 0.0;
-  st->reserved = 0;
+  st->adam_step_size = 0.0f, st->adam_bc2_sqrt = 0.0f;
 }
 
 __global__ void iter_begin_kernel(catppo_iter_state* st, double lr0, double num_iterations, int schedule) {

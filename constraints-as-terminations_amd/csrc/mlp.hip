@@ -1644,14 +1644,74 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float
 }
 
 // ------------------------------------------------------------------------------- clip + Adam
-__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n,
-                                                             double* __restrict__ part) {
-  __shared__ double sm[4];
+// Elementwise tails of an optimiser step.  Both are a few hundred K elements behind a launch: what they cost is load
+// round trips in sequence, so a thread takes FOUR consecutive elements per pass (16-byte accesses when the arrays are
+// 16-byte aligned, as torch's are) instead of one element on each of four passes.
+__device__ __forceinline__ double sqnorm_of_thread(const float* __restrict__ g, int64_t n) {
   double a = 0.0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  int64_t done = 0;
+  if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 x = reinterpret_cast<const float4*>(g)[i];
+      a += (double)x.x * (double)x.x;
+      a += (double)x.y * (double)x.y;
+      a += (double)x.z * (double)x.z;
+      a += (double)x.w * (double)x.w;
+    }
+    done = n4 * 4;
+  }
+  for (int64_t e = done + tid; e < n; e += nth) {
     const double v = (double)g[e];
     a += v * v;
   }
+  return a;
+}
+
+struct AdamCoef {
+  float coef, one_m_b1, b2, one_m_b2, eps, step_size, bc2_sqrt;
+};
+// clip + Adam of one element: g <- g*coef; exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2);
+// param.addcdiv_(exp_avg, sqrt(exp_avg_sq)/sqrt(bc2) + eps, -step_size)
+__device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, const AdamCoef& c) {
+  const float gr = g * c.coef;
+  g = gr;
+  m = m + (gr - m) * c.one_m_b1;
+  float vv = v * c.b2;
+  vv = vv + c.one_m_b2 * gr * gr;
+  v = vv;
+  const float denom = sqrtf(vv) / c.bc2_sqrt + c.eps;
+  p = p + (-c.step_size * m) / denom;
+}
+__device__ __forceinline__ void adam_all(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                         float* __restrict__ v, int64_t n, const AdamCoef& c) {
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+  int64_t done = 0;
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+        reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 P = reinterpret_cast<float4*>(p)[i], Gd = reinterpret_cast<float4*>(g)[i];
+      float4 Mo = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+      adam_elem(P.x, Gd.x, Mo.x, V.x, c);
+      adam_elem(P.y, Gd.y, Mo.y, V.y, c);
+      adam_elem(P.z, Gd.z, Mo.z, V.z, c);
+      adam_elem(P.w, Gd.w, Mo.w, V.w, c);
+      reinterpret_cast<float4*>(g)[i] = Gd;
+      reinterpret_cast<float4*>(m)[i] = Mo;
+      reinterpret_cast<float4*>(v)[i] = V;
+      reinterpret_cast<float4*>(p)[i] = P;
+    }
+    done = n4 * 4;
+  }
+  for (int64_t e = done + tid; e < n; e += nth) adam_elem(p[e], g[e], m[e], v[e], c);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, int64_t n,
+                                                             double* __restrict__ part) {
+  __shared__ double sm[4];
+  double a = sqnorm_of_thread(g, n);
   a = wave_sum_d(a);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
   __syncthreads();
@@ -1676,19 +1736,8 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, f
     }
   }
   __syncthreads();
-  const float coef = s_coef;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const float gr = g[e] * coef;
-    g[e] = gr;
-    float mm = m[e];
-    mm = mm + (gr - mm) * one_m_b1;                   // exp_avg.lerp_(grad, 1-beta1)
-    float vv = v[e] * beta2;
-    vv = vv + one_m_b2 * gr * gr;                     // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    m[e] = mm;
-    v[e] = vv;
-    p[e] = p[e] + (-step_size * mm) / denom;          // param.addcdiv_(exp_avg, denom, -step_size)
-  }
+  const AdamCoef c{s_coef, one_m_b1, beta2, one_m_b2, eps, step_size, bc2_sqrt};
+  adam_all(p, g, m, v, n, c);
 }
 
 template <typename F>
@@ -2203,20 +2252,27 @@ extern "C" int catppo_clip_adam(catppo_ctx* ctx, float* params, float* grad, flo
 namespace {
 __global__ __launch_bounds__(256) void sqnorm_partial_step_kernel(const float* __restrict__ g, int64_t n,
                                                                   double* __restrict__ part,
-                                                                  catppo_iter_state* __restrict__ st) {
+                                                                  catppo_iter_state* __restrict__ st, double beta1,
+                                                                  double beta2) {
   __shared__ double sm[4];
-  double a = 0.0;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const double v = (double)g[e];
-    a += v * v;
+  // one lane of the launch advances the step count and prepares Adam's bias corrections for the NEXT launch
+  // (clip_adam_dev_kernel) while everybody else is waiting for their gradient loads: two double-precision pow() that
+  // used to sit at the head of every workgroup of the Adam launch.
+  // torch.optim.Adam: bias_correction = 1 - beta ** step (Python doubles), step_size = lr / bias_correction1
+  if (blockIdx.x == 0 && threadIdx.x == 64) {
+    const int64_t step_i = st->adam_step + 1;
+    const double step = (double)step_i;
+    const double bc1 = 1.0 - pow(beta1, step);
+    const double bc2 = 1.0 - pow(beta2, step);
+    st->adam_step = step_i;
+    st->adam_step_size = (float)(st->lr / bc1);
+    st->adam_bc2_sqrt = (float)sqrt(bc2);
   }
+  double a = sqnorm_of_thread(g, n);
   a = wave_sum_d(a);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
-    if (blockIdx.x == 0) st->adam_step = st->adam_step + 1;   // read by the NEXT launch (clip_adam_dev_kernel)
-  }
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 __global__ __launch_bounds__(256) void clip_adam_dev_kernel(float* __restrict__ p, float* __restrict__ g,
@@ -2224,7 +2280,7 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(float* __restrict__ 
                                                             const double* __restrict__ norm_part, int n_part,
                                                             float max_norm, double beta1, double beta2, float eps,
                                                             const catppo_iter_state* __restrict__ st) {
-  __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+  __shared__ float s_coef;
   if (threadIdx.x < 64) {
     double a = 0.0;
     for (int b = threadIdx.x; b < n_part; b += 64) a += norm_part[b];
@@ -2233,29 +2289,12 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(float* __restrict__ 
       const float total = (float)sqrt(a);
       const float c = max_norm / (total + 1e-6f);
       s_coef = c > 1.0f ? 1.0f : c;
-      // torch.optim.Adam: bias_correction = 1 - beta ** step (Python doubles), step_size = lr / bias_correction1
-      const double step = (double)st->adam_step;
-      const double bc1 = 1.0 - pow(beta1, step);
-      const double bc2 = 1.0 - pow(beta2, step);
-      s_step_size = (float)(st->lr / bc1);
-      s_bc2_sqrt = (float)sqrt(bc2);
     }
   }
+  const float step_size = st->adam_step_size, bc2_sqrt = st->adam_bc2_sqrt;   // sqnorm_partial_step_kernel wrote them
   __syncthreads();
-  const float coef = s_coef, step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
-  const float b2 = (float)beta2, one_m_b1 = (float)(1.0 - beta1), one_m_b2 = (float)(1.0 - beta2);
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
-    const float gr = g[e] * coef;
-    g[e] = gr;
-    float mm = m[e];
-    mm = mm + (gr - mm) * one_m_b1;
-    float vv = v[e] * b2;
-    vv = vv + one_m_b2 * gr * gr;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    m[e] = mm;
-    v[e] = vv;
-    p[e] = p[e] + (-step_size * mm) / denom;
-  }
+  const AdamCoef c{s_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, step_size, bc2_sqrt};
+  adam_all(p, g, m, v, n, c);
 }
 }  // namespace
 
@@ -2270,7 +2309,8 @@ extern "C" int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad,
   CATPPO_NEED_WS(ctx, part);
   int nb = (int)cdiv64(n_flat, 256 * 4);
   if (nb > kNormBlocks) nb = kNormBlocks;
-  hipLaunchKernelGGL(sqnorm_partial_step_kernel, dim3(nb), dim3(256), 0, s, (const float*)grad, n_flat, part, state);
+  hipLaunchKernelGGL(sqnorm_partial_step_kernel, dim3(nb), dim3(256), 0, s, (const float*)grad, n_flat, part, state, beta1,
+                     beta2);
   CATPPO_CHECK_LAUNCH(ctx);
   int nblk = (int)cdiv64(n_flat, 256 * 4);
   if (nblk > 1024) nblk = 1024;

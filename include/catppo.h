@@ -369,7 +369,8 @@ typedef struct catppo_iter_state {
   double kl_mark;     /* diag[4] (approx-KL sum) at the last catppo_kl_adaptive_lr of this iteration */
   double n_mark;      /* diag[7] (minibatch count) at that point */
   double last_kl;     /* KL the schedule last saw (diagnostics) */
-  int64_t reserved;
+  float adam_step_size;  /* lr / (1 - beta1^step) of the step catppo_clip_adam_dev is taking (written by its first launch, */
+  float adam_bc2_sqrt;   /* sqrt(1 - beta2^step)                      read by its second; scratch, not an input)     */
 } catppo_iter_state;
 
 /* state <- {seed, iteration 0, adam_step 0, lr} */
