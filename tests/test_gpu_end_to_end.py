@@ -168,3 +168,42 @@ def test_config5_env_count_full_constraints_7_envs_and_ragged():
     smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
     trainer, orc, outs = smoke_impl.run_pair(num_envs=7, num_steps=5, minibatch=35, epochs=1, iters=2, six_terms=False)
     smoke_impl.compare(trainer, orc, outs[-1], tol_scale=2.0)
+
+
+def test_cross_workgroup_handshake_of_the_fused_step_1500_steps():
+    """The "last workgroup folds" hand-shake of rollout_pre exchanges its partial rows with device-scope atomic stores /
+    loads ordered by a completion wait - no device-scope fences.  A stale read there would show up as
+    a wrong column maximum or moment sum in SOME step: 1500 consecutive fused env steps at cfg2's size, the exchange
+    record of every step recomputed independently from the constraint tile and the raw observations the same launch
+    wrote / read.  Column maxima bit-exact (max is order independent), fp64 moment sums to 1e-12 relative."""
+    import smoke_impl
+    from cat_envs.shim import make
+    from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+    N, T, S = 4096, 24, 1500
+    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(N, T, 16384, 1, 1, (256, 256, 256), True, obs_dim=48, stream_steps=64)
+    env = make(task, cfg=env_cfg)
+    tr = PPOTrainer(env, agent_cfg)
+    assert tr.sink is not None
+    env_u = env.unwrapped
+    cm = env_u.constraint_manager
+    g = torch.Generator(device="cuda").manual_seed(5)
+    acts = torch.randn(T, N, tr.A, device="cuda", generator=g)
+    K, D = cm.cat._p_cstr.shape[1], env_u.obs_dim
+    got_max, got_sum = torch.empty(S, K, device="cuda"), torch.empty(S, 2 * D, dtype=torch.float64, device="cuda")
+    ref_max, ref_sum = torch.empty_like(got_max), torch.empty_like(got_sum)
+    obs_raw = env_u.sim.view("obs")
+    for k in range(S):
+        tr.sink.step = k % T
+        env_u.step_into(acts[k % T], tr.sink)
+        got_max[k].copy_(env_u._xchg_views[0])
+        got_sum[k].copy_(env_u._xchg_views[1])
+        ref_max[k].copy_(cm.cat._p_cstr.max(dim=0).values.clamp_min(1e-6))
+        x = obs_raw.double()
+        ref_sum[k, :D].copy_(x.sum(0))
+        ref_sum[k, D:].copy_((x * x).sum(0))
+    torch.cuda.synchronize()
+    assert torch.isfinite(got_max).all() and float(ref_max.max()) > 1e-3
+    bad = (got_max != ref_max).any(dim=1).nonzero().flatten().tolist()
+    assert not bad, f"column maxima differ in steps {bad[:10]} (of {len(bad)})"
+    rel = ((got_sum - ref_sum).abs() / ref_sum.abs().clamp_min(1.0)).max(dim=1).values
+    assert float(rel.max()) < 1e-12, (float(rel.max()), int(rel.argmax()))
