@@ -380,8 +380,7 @@ struct PostArgs {
   const double* x_sums;
   int x_records;          // > 1: x_colmax / x_sums point at record 0 of `x_records` gathered records, x_stride bytes apart
   int64_t x_stride;
-  double* reset_part;     // [grid][n_terms][2]
-  double* reset_cnt;      // [grid]
+  double* reset_part;     // [grid][2 n_terms + 1]: per term {sum violation, sum probability}, then the reset count
   unsigned int* ticket;
 };
 
@@ -513,8 +512,8 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const int t = threadIdx.x;
     double sa = 0.0, sb = 0.0;
     for (int e = 0; e < kPostRows; ++e) sa += red[t * kPostRows + e], sb += red[nt * kPostRows + t * kPostRows + e];
-    xwg_store(a.reset_part + ((int64_t)blockIdx.x * nt + t) * 2, sa);
-    xwg_store(a.reset_part + ((int64_t)blockIdx.x * nt + t) * 2 + 1, sb);
+    xwg_store(a.reset_part + (int64_t)blockIdx.x * (2 * nt + 1) + 2 * t, sa);
+    xwg_store(a.reset_part + (int64_t)blockIdx.x * (2 * nt + 1) + 2 * t + 1, sb);
   }
   // ---- per env: probability, reward, dones (cat_env.py:102-107,118-121), rollout rows, reset bookkeeping
   if (threadIdx.x < rows) {
@@ -530,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const bool rs = a.reset[i] != 0;
     {   // envs of this tile that reset: rows <= 32 live in the first half of wave 0
       const unsigned long long mask = __ballot(rs);
-      if (threadIdx.x == 0) xwg_store(a.reset_cnt + blockIdx.x, (double)__popcll(mask));
+      if (threadIdx.x == 0) xwg_store(a.reset_part + (int64_t)blockIdx.x * (2 * nt + 1) + 2 * nt, (double)__popcll(mask));
     }
     const float dn = rs ? 1.0f : p;
     if (a.dones) a.dones[i] = dn;
@@ -565,17 +564,19 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     if (threadIdx.x == 0) a.obs_count[0] = s_tot;
   }
   if (a.log_out != nullptr) {
+    // one pass over the partial rows {sum violation, sum probability per term | number of envs that reset}: the rows
+    // come from the coherence point (~3.5 us per round trip) - the count used to be its own fold in front of this one
     const int nblk = gridDim.x;
-    __shared__ double s_n;
-    block_fold<double>(a.reset_cnt, nblk, 1, 0.0, [](double x, double y) { return x + y; }, red,
-                       [&](int, double v) { s_n = v; });
-    __syncthreads();
-    const double n = s_n;
-    block_fold<double>(a.reset_part, nblk, 2 * nt, 0.0, [](double x, double y) { return x + y; }, red,
-                       [&](int c, double v) {     // column c = 2*t (violation) | 2*t+1 (probability)
-                         if (n > 0.0) a.log_out[c] = (c & 1) ? (float)(v / n) : (float)(v / n) * 100.0f;
-                         else if (a.log_prev != nullptr) a.log_out[c] = a.log_prev[c];
-                       });
+    __shared__ double s_sum[2 * kMaxTerms + 1];
+    block_fold<double>(a.reset_part, nblk, 2 * nt + 1, 0.0, [](double x, double y) { return x + y; }, red,
+                       [&](int c, double v) { s_sum[c] = v; });
+    const double n = s_sum[2 * nt];
+    if (threadIdx.x < 2 * nt) {
+      const int c = threadIdx.x;                  // column c = 2*t (violation) | 2*t+1 (probability)
+      const double v = s_sum[c];
+      if (n > 0.0) a.log_out[c] = (c & 1) ? (float)(v / n) : (float)(v / n) * 100.0f;
+      else if (a.log_prev != nullptr) a.log_out[c] = a.log_prev[c];
+    }
   }
   RL_TL(1, 4);
 }
@@ -691,10 +692,8 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   if (lds > 140 * 1024) return catppo_fail(ctx, CATPPO_E_ARG, "rollout_post: K=%d / D=%d too wide for one LDS tile", K, D);
   const int nblk = (int)cdiv64(a->N, kPostRows);
   WsCarver ws(ctx);
-  double* rpart = ws.take<double>((uint64_t)nblk * nt * 2);
-  double* rcnt = ws.take<double>((uint64_t)nblk);
+  double* rpart = ws.take<double>((uint64_t)nblk * (nt * 2 + 1));
   CATPPO_NEED_WS(ctx, rpart);
-  CATPPO_NEED_WS(ctx, rcnt);
   PostArgs p{};
   p.N = a->N, p.A = a->A, p.D = D, p.K = K, p.n_terms = nt;
   p.cstr = a->cstr;
@@ -715,7 +714,7 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   p.x_sums = reinterpret_cast<const double*>(static_cast<const char*>(xbase) + xchg_sum_offset(K));
   p.x_records = (a->xchg_records > 1 && a->xchg_gathered != nullptr) ? a->xchg_records : 1;
   p.x_stride = (int64_t)(xchg_sum_offset(K) + (uint64_t)2 * (a->D > 0 ? a->D : 1) * sizeof(double));
-  p.reset_part = rpart, p.reset_cnt = rcnt;
+  p.reset_part = rpart;
   p.ticket = ctx->tickets + catppo_ctx::kTicketPost;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_post_kernel),
