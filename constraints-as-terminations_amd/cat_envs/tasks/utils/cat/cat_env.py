@@ -332,11 +332,12 @@ class CaTEnv:
         rc = lib.catppo_rollout_pre(h, self._rstep_ref, stream)
         if rc:
             nat._ok(rc)
-        # env-sharded runs: the two halves of the exchange buffer are reduced independently.  The CaT column maxima
-        # only in exact mode (cm.dist_group, set by the trainer under dist_exact); the observation moment sums
-        # whenever the consumer's normaliser is global (sink.obs_group) - its divisor obs_rows_total is then the
-        # global env count, so the sums MUST be global too (with dist_exact=False they used to stay local while the
-        # divisor was global: the running mean shrank by 1/world per update).
+        # env-sharded runs exchange the record rollout_pre just wrote {CaT column maxima | observation moment sums}.
+        # The maxima travel only in exact mode (cm.dist_group, set by the trainer under dist_exact); the moment sums
+        # whenever the consumer's normaliser is global (sink.obs_group) - its divisor obs_rows_total is then the global
+        # env count, so the sums MUST be global too (with dist_exact=False they once stayed local while the divisor was
+        # global: the running mean shrank by 1/world per update).  Both wanted (exact mode): ONE all-gather of the
+        # record, folded by rollout_post; only one of them: an all-reduce of that half.
         par = self._parallel
         group, obs_group = cm.dist_group, getattr(sink, "obs_group", None)
         g_on = group is not None and par.active(group)
