@@ -1,8 +1,12 @@
 """bench.py - env-steps/s of the CaT-PPO hot path on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps 20 --warmup 5          (N > 1 and no launcher around it: bench.py starts the N ranks
+                                                             itself, `torch.distributed.run --nnodes=1 --nproc-per-node N`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W        (the driver's form; same result)
+A line is only printed when the ranks that ran equal --gpus.  More ranks than visible GPUs (a one-GPU box) is allowed as
+a LAUNCHER PROOF, not a scaling number: the ranks then share devices and exchange through gloo with host staging (RCCL
+refuses two ranks on one device), and the line says so (`physical_gpus`, `ranks_share_gpus`, `collectives`).
 
 A "step" is ONE full CaT-PPO iteration (BASELINE.json metric): T x [policy/value forward + Philox action
 sample, constraint-term evaluation + CaT step + reward / dones epilogue + reset statistics, rollout-buffer rows, obs
@@ -238,6 +242,26 @@ def gae_roofline(nat, T, N, reps=50, mode=None):
             "mode": {None: "serial_exact", native.GAE_SCAN: "scan", native.GAE_SERIAL: "serial_exact"}[mode]}
 
 
+def self_launch(n_ranks: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks of this node here -
+    the same command line under torch.distributed.run, one process per rank, rendezvous on 127.0.0.1 (the container
+    hostname may not resolve).  Rank 0's JSON line passes through on stdout; returns the launcher's exit code.
+    Reference precedent for a self-contained distributed entry point: scripts/skrl/train.py:28-30,116-117."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["CATPPO_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    print(f"[bench] --gpus {n_ranks} without a launcher: starting {n_ranks} ranks: {' '.join(cmd)}", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,30 +275,57 @@ def main():
                          "the bf16 peak).  bf16 = operands rounded to bf16 (BASELINE config 5): NOT a parity mode")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="PPO cfg override, e.g. --set graph_update=True --set rng=torch --set fused_rollout=False")
-    ap.add_argument("--profile-tag", default="r3", help="prefix of the PMC / kernel-trace summaries under profiles/")
+    ap.add_argument("--profile-tag", default="r4", help="prefix of the PMC / kernel-trace summaries under profiles/")
     ap.add_argument("--shard-of", type=int, default=0, metavar="W",
                     help="single process, no collectives: run ONE rank's share of a strong-scaling workload as if the "
                          "world had W ranks (compute side of the scaling curve on a one-GPU box)")
     ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--print-launch", action="store_true",
+                    help="print the torch.distributed.run command a bare `--gpus N` would start, and exit")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        if a.print_launch:
+            print(" ".join([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+                            "--master-addr", "127.0.0.1", "--master-port", "<free port>", os.path.abspath(__file__),
+                            *[x for x in sys.argv[1:] if x != "--print-launch"]]))
+            return 0
+        return self_launch(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        # never a line whose n_gpus differs from what was asked for
+        if rank == 0:
+            print(f"[bench] --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to run "
+                  f"(use `python bench.py --gpus {a.gpus}` or --nproc-per-node {a.gpus})", file=sys.stderr)
+        return 2
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        print("[bench] no HIP device visible: the hot path runs on MI355X only (no CPU fallback)", file=sys.stderr)
+        return 3
+    shared = world > n_dev                # more ranks than GPUs: launcher proof on a small box, ranks share devices
+    dev_index = local % n_dev
     if world > 1 or os.environ.get("CATPPO_FORCE_DIST") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        # torch.distributed is the rendezvous (unique-id exchange, barrier); the data-path collectives are
-        # catppo_allreduce on libcatppo's own RCCL communicator
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))   # nccl == RCCL on ROCm
+        torch.cuda.set_device(dev_index)
+        if shared:
+            # RCCL refuses two ranks on one device: gloo process group, device operands staged through host memory by
+            # cat_envs.parallel (the transport of tests/test_gpu_two_rank_trainer.py) - correct, slow, never production
+            os.environ["CATPPO_NATIVE_COMM"] = "0"
+            torch.distributed.init_process_group("gloo")
+        else:
+            # torch.distributed is the rendezvous (unique-id exchange, barrier); the data-path collectives are
+            # catppo_allreduce on libcatppo's own RCCL communicator
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", dev_index))   # nccl == RCCL on ROCm
     else:
         torch.cuda.set_device(0)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run", file=sys.stderr)
 
     import ast
     overrides = {}
@@ -290,7 +341,7 @@ def main():
     # Manager" table) goes to stderr
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):
-        env, trainer, agent_cfg = build(a.workload, a.seed + rank, local, a.mlp_precision, shard_world, rank, overrides)
+        env, trainer, agent_cfg = build(a.workload, a.seed + rank, dev_index, a.mlp_precision, shard_world, rank, overrides)
     nat = trainer.nat
     from cat_envs import parallel
 
@@ -329,7 +380,7 @@ def main():
     trainer.time_phases = False
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        parallel.allreduce_max_(t)        # RCCL, or host-staged gloo when the ranks share a device
         dt = float(t)
     env_total = trainer.n_envs_global if world > 1 else float(trainer.N)
     steps_total = env_total * w["num_steps"] * a.steps
@@ -342,6 +393,30 @@ def main():
         trainer.run_iteration(log=False)
     barrier()
     dt_nolog = time.perf_counter() - t1
+
+    # device time inside the exchange points of one iteration (all-gather of the env-step record, normaliser / advantage
+    # moments, gradient all-reduce, diagnostics): HIP events around every collective cat_envs.parallel issues, on the
+    # stream it is issued on.  Collectives captured in the update-phase graph, and gradient buckets reduced inside the
+    # library beside the backward launches, cannot be bracketed from here: this pass runs the same iteration with both
+    # switched off, i.e. it reports the SERIALISED wire time (what overlap can at most hide), outside the timed region.
+    comm = None
+    if parallel.active():
+        g_was, ov_was = trainer.graph_update, trainer.grad_overlap
+        trainer.graph_update = False
+        if ov_was:
+            trainer.grad_overlap = nat.set_grad_overlap(False)
+        trainer.run_iteration(log=True)
+        barrier()
+        parallel.comm_timing_begin()
+        n_comm_it = 2
+        for _ in range(n_comm_it):
+            trainer.run_iteration(log=True)
+        comm = parallel.comm_timing_end()
+        comm["iterations"] = n_comm_it
+        barrier()
+        trainer.graph_update = g_was
+        if ov_was:
+            trainer.grad_overlap = nat.set_grad_overlap(True)
 
     if rank == 0:
         M = trainer.M
@@ -375,7 +450,8 @@ def main():
         from cat_envs import native
         out = {
             "metric": "env-steps/s CaT-PPO iteration (rollout + GAE + PPO update)", "value": value,
-            "unit": "env-steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "unit": "env-steps/s", "n_gpus": world, "physical_gpus": min(world, n_dev), "ranks_share_gpus": shared,
+            "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
             "scaling": "strong" if w.get("strong") else "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32",
@@ -389,17 +465,30 @@ def main():
                        "parallelism": f"env-sharded dp{world}, " + ("catppo_allreduce (RCCL)" if
                                       parallel.native_comm_active() or world == 1 else "torch.distributed all_reduce (RCCL)")
                                       + " of the flat gradient",
-                       "rccl_world": nat.comm_world if parallel.native_comm_active() else (world if world > 1 else 0),
+                       "rccl_world": nat.comm_world if parallel.native_comm_active() else
+                                     (world if (world > 1 and not shared) else 0),
                        "collectives": "libcatppo C ABI (librccl)" if parallel.native_comm_active() else
-                                      ("torch.distributed" + (f" (native set-up failed: {parallel.native_comm_error()})"
+                                      ("gloo, device operands staged through host memory (ranks share a GPU: launcher "
+                                       "proof, not a scaling number)" if shared else
+                                       "torch.distributed" + (f" (native set-up failed: {parallel.native_comm_error()})"
                                                               if parallel.native_comm_error() else "")
                                        if world > 1 else "none"),
+                       "self_launched": os.environ.get("CATPPO_BENCH_SELF_LAUNCHED") == "1",
+                       "grad_overlap": trainer.grad_overlap, "graph_fallback": trainer.graph_fallback,
                        "timed_region": "K x run_iteration(log=True): includes the per-iteration diagnostics read-back",
                        "simulated_shard_of_world": a.shard_of if a.shard_of > 0 else None,
                        "rng": trainer.rng, "fused_rollout": trainer.sink is not None,
                        "graph_update": trainer.graph_update, "graph_nodes": trainer.graph_nodes,
                        "overrides": overrides},
             "ms_per_step_no_readback": 1e3 * dt_nolog / a.steps,
+            "comm_ms_per_iteration": None if comm is None else comm["ms"] / comm["iterations"],
+            "comm": None if comm is None else {
+                "collectives_per_iteration": comm["calls"] / comm["iterations"],
+                "bytes_per_iteration": comm["bytes"] / comm["iterations"],
+                "ms_by_kind_per_iteration": {k: v[0] / comm["iterations"] for k, v in comm["by_kind"].items()},
+                "calls_by_kind_per_iteration": {k: v[1] / comm["iterations"] for k, v in comm["by_kind"].items()},
+                "measured": "HIP events around every exchange point of an un-graphed, un-overlapped iteration after the "
+                            "timed region (serialised wire time)"},
             "phases_device_ms": phases,
             "iteration_tflops": it_flops / (1e9 * dt / a.steps) / 1e3,
             "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (grouped fp32-MFMA forward GEMM launches, the last one "
@@ -410,6 +499,9 @@ def main():
                          "executed_over_algorithmic_flops": mfma_flops_factor,
                          "traffic": traffic, "avg_launch_us": grad_us, "launches_timed": len(ev),
                          "dominant_kernel_us_profiled": prof_us, "profiled_source": prof_src,
+                         # the same FLOPs over the COMMITTED rocprofv3 duration of the group (profiler on, another box)
+                         "frac_profiled": None if not prof_us else
+                                          flops_per_launch / prof_us / 1e6 * mfma_flops_factor / peak,
                          "timed": "eager replay after the timed region (update phase runs from a hipGraph)"
                                   if trainer.graph_update else "HIP events inside the timed region",
                          "flops_per_launch": flops_per_launch,
@@ -435,8 +527,10 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        assert out["n_gpus"] == a.gpus
         print(json.dumps(out), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

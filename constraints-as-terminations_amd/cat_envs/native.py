@@ -185,6 +185,9 @@ _SIGNATURES = {
     "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "catppo_rlg_episode_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    # ---- ABI 0.4
+    "catppo_set_grad_overlap": (C.c_int, [_vp, C.c_int]),
+    "catppo_grad_overlap_active": (C.c_int, [_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -698,6 +701,16 @@ class Native:
 
     def comm_destroy(self):
         self._ok(self.lib.catppo_comm_destroy(self.h))
+
+    def set_grad_overlap(self, on: bool) -> bool:
+        """gradient all-reduce in per-layer buckets on the library's side stream, under the backward launches
+        (ABI 0.4); returns whether the next ``ppo_minibatch_grad*`` call will reduce its own buckets"""
+        self._ok(self.lib.catppo_set_grad_overlap(self.h, int(bool(on))))
+        return bool(self.lib.catppo_grad_overlap_active(self.h))
+
+    @property
+    def grad_overlap_active(self) -> bool:
+        return bool(self.lib.catppo_grad_overlap_active(self.h))
 
     def allreduce(self, t: torch.Tensor, op: int = SUM):
         self._ok(self.lib.catppo_allreduce(self.h, _p(_chk(t, t.dtype, "allreduce operand")), t.numel(), self._dt(t),

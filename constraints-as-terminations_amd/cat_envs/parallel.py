@@ -131,17 +131,67 @@ def _host_staged(t: torch.Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def _collective(t: torch.Tensor, group, native_call, torch_call):
+#: [(kind, bytes, start event, end event)] while comm_timing_begin() ... comm_timing_end() brackets a region (bench.py's
+#: ``comm_ms_per_iteration``), else None.  HIP events on the stream the collective is enqueued on.
+_timing = None
+
+
+def comm_timing_begin():
+    """start recording one HIP-event pair around every device-tensor exchange point issued from Python"""
+    global _timing
+    _timing = []
+
+
+def comm_timing_end():
+    """stop recording; returns {"ms": total device milliseconds between the event pairs, "calls": n, "bytes": operand
+    bytes, "by_kind": {kind: [ms, calls]}} (synchronises)"""
+    global _timing
+    rec, _timing = _timing or [], None
+    if rec:
+        torch.cuda.synchronize()
+    out = {"ms": 0.0, "calls": len(rec), "bytes": 0, "by_kind": {}}
+    for kind, nbytes, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        out["ms"] += ms
+        out["bytes"] += nbytes
+        k = out["by_kind"].setdefault(kind, [0.0, 0])
+        k[0] += ms
+        k[1] += 1
+    return out
+
+
+class _timed:
+    """brackets one exchange point with HIP events when comm timing is on (device operands only)"""
+
+    def __init__(self, kind, t):
+        self.on = _timing is not None and t.is_cuda
+        self.kind, self.nbytes = kind, t.numel() * t.element_size()
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            if _timing is not None:
+                _timing.append((self.kind, self.nbytes, self.e0, self.e1))
+        return False
+
+
+def _collective(t: torch.Tensor, group, native_call, torch_call, kind="allreduce"):
     if not active(group):
         return t
-    if _use_native(t, group):
-        native_call(t)
-    elif _host_staged(t, group):
-        h = t.detach().cpu()
-        torch_call(h)
-        t.copy_(h)
-    else:
-        torch_call(t)
+    with _timed(kind, t):
+        if _use_native(t, group):
+            native_call(t)
+        elif _host_staged(t, group):
+            h = t.detach().cpu()
+            torch_call(h)
+            t.copy_(h)
+        else:
+            torch_call(t)
     return t
 
 
@@ -157,7 +207,7 @@ def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
 
 def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     return _collective(t, group, lambda x: _native.broadcast(x, src),
-                       lambda x: dist.broadcast(x, src=src, group=group))
+                       lambda x: dist.broadcast(x, src=src, group=group), kind="broadcast")
 
 
 def allgather_bytes_(send: torch.Tensor, recv: torch.Tensor, group=None) -> torch.Tensor:
@@ -167,14 +217,15 @@ def allgather_bytes_(send: torch.Tensor, recv: torch.Tensor, group=None) -> torc
     if not active(group):
         recv[:send.numel()].copy_(send)
         return recv
-    if _native is not None and send.is_cuda and group in (None, dist.group.WORLD):
-        _native.allgather(send, recv)
-    elif _host_staged(send, group):
-        h = torch.empty(recv.numel(), dtype=torch.uint8)
-        dist.all_gather_into_tensor(h, send.detach().cpu(), group=group)
-        recv.copy_(h)
-    else:
-        dist.all_gather_into_tensor(recv, send, group=group)
+    with _timed("allgather", recv):
+        if _native is not None and send.is_cuda and group in (None, dist.group.WORLD):
+            _native.allgather(send, recv)
+        elif _host_staged(send, group):
+            h = torch.empty(recv.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(h, send.detach().cpu(), group=group)
+            recv.copy_(h)
+        else:
+            dist.all_gather_into_tensor(recv, send, group=group)
     return recv
 
 

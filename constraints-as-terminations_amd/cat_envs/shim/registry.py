@@ -78,7 +78,15 @@ def hydra_task_config(task_name: str, agent_cfg_entry_point: str):
         def wrapper(*args, **kwargs):
             env_cfg = load_cfg_from_registry(task_name, "env_cfg_entry_point")
             agent_cfg = load_cfg_from_registry(task_name, agent_cfg_entry_point)
-            apply_overrides({"env": env_cfg, "agent": agent_cfg}, [a for a in sys.argv[1:] if not a.startswith("-")])
+            # only `key=value` tokens are overrides.  Anything else left on the command line (the VALUE of an unknown
+            # `--flag value` pair that parse_known_args passed through, a stray positional) is reported and skipped, as
+            # train.py did before the decorator existed - it must not abort the run as a malformed override
+            tokens = [a for a in sys.argv[1:] if not a.startswith("-")]
+            stray = [a for a in tokens if "=" not in a]
+            if stray:
+                print(f"[WARN] ignoring command-line tokens that are neither flags nor key=value overrides: {stray}",
+                      file=sys.stderr)
+            apply_overrides({"env": env_cfg, "agent": agent_cfg}, [a for a in tokens if "=" in a])
             return func(env_cfg, agent_cfg, *args, **kwargs)
         return wrapper
     return decorator

@@ -345,10 +345,12 @@ class CaTEnv:
         if g_on and o_on and group is obs_group:
             # exact mode: ONE collective per env step - all-gather this rank's record {colmax | sums}; rollout_post folds
             # the records of all ranks itself (MAX is exact, the sums run in rank order on every rank)
-            if self._xchg_all is None:
-                self._xchg_all = torch.zeros(par.world_size(group) * self._xchg.numel(), dtype=torch.uint8,
-                                             device=self.device)
-                st.xchg_gathered, st.xchg_records = self._xchg_all.data_ptr(), par.world_size(group)
+            w = par.world_size(group)
+            if self._xchg_all is None or self._xchg_all.numel() != w * self._xchg.numel():
+                self._xchg_all = torch.zeros(w * self._xchg.numel(), dtype=torch.uint8, device=self.device)
+            # set on EVERY pass: a step through the other branch (another sink / trainer on the same env with a different
+            # dist_exact or obs group) leaves xchg_records = 0, and rollout_post would then fold the local record only
+            st.xchg_gathered, st.xchg_records = self._xchg_all.data_ptr(), w
             par.allgather_bytes_(self._xchg, self._xchg_all, group)
         else:
             st.xchg_records = 0

@@ -421,10 +421,26 @@ class PPOTrainer:
             # gaps the graph removes); round 2 only enabled it up to 4096 rows
             g = True
         dist_on_torch = parallel.active() and not parallel.native_comm_active()
-        # RCCL collectives inside a captured graph are exercised on a world of one here (a one-GPU box); with real
-        # peers they stay opt-in (CATPPO_GRAPH_COMM=1) until measured on a multi-GPU node
-        dist_in_graph_ok = self.world == 1 or os.environ.get("CATPPO_GRAPH_COMM") == "1"
+        # RCCL collectives sit inside the captured graph by default at every world size (round 4; they are stream
+        # operations under the C ABI).  If the capture or the first replay fails on some node the update phase falls
+        # back to eager launches and says so (``graph_fallback``, stderr, bench.py's JSON line) instead of failing the
+        # run; CATPPO_GRAPH_COMM=0 keeps collectives out of graphs altogether.
+        dist_in_graph_ok = self.world == 1 or os.environ.get("CATPPO_GRAPH_COMM", "1") != "0"
         self.graph_update = bool(g) and self.rng == "device" and not dist_on_torch and dist_in_graph_ok
+        #: why the update phase left the graph path (None: it did not)
+        self.graph_fallback = None
+        # gradient all-reduce in per-layer buckets on the library's side stream, under the backward launches of the
+        # layers below (catppo_set_grad_overlap; cf. skrl/ppo.py:534-537, which reduces after the whole backward).
+        # Needs libcatppo's own communicator; default: on whenever there are real peers.
+        go = getattr(c, "grad_overlap", None)
+        env_go = os.environ.get("CATPPO_GRAD_OVERLAP")
+        if env_go is not None:
+            go = env_go == "1"
+        if go is None:
+            go = self.world > 1
+        self.grad_overlap = False
+        if parallel.active() and parallel.native_comm_active():
+            self.grad_overlap = self.nat.set_grad_overlap(bool(go))
         self._graph_id = None
         self.graph_nodes = 0
         self.stream = torch.cuda.Stream(device=dev) if self.graph_update else None
@@ -583,7 +599,8 @@ class PPOTrainer:
                 nat.ppo_minibatch_grad_packed(a.shape, self.hp, a.flat, self._x_g[start:], self._act_g[start:],
                                               self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
                                               vmean, vvar, adv_stats, self.grad, self.diag)
-                parallel.allreduce_sum_(self.grad)              # RCCL SUM of the flat gradient over xGMI
+                if not self.grad_overlap:                       # (else: reduced bucket by bucket inside the call above)
+                    parallel.allreduce_sum_(self.grad)          # RCCL SUM of the flat gradient over xGMI
                 nat.clip_adam_dev(a.flat, self.grad, self.exp_avg, self.exp_avg_sq, a.layout.n_flat,
                                   c.max_grad_norm, 0.9, 0.999, 1e-5, self.state)
             if self.lr_schedule == "adaptive":
@@ -614,19 +631,34 @@ class PPOTrainer:
                     return
                 except RuntimeError:                             # workspace grew: the graph was dropped
                     self._graph_id = None
-            self.nat.graph_begin()
             try:
-                self._graph_steps = self._update_body(None)
-            except BaseException:
-                # a failure between begin and end leaves a PARTIAL capture: never instantiate or replay it, and let
-                # the original error surface (ending the capture may itself fail once the capture is invalidated)
-                self.nat.graph_abort()
+                self.nat.graph_begin()
+                try:
+                    self._graph_steps = self._update_body(None)
+                except BaseException:
+                    # a failure between begin and end leaves a PARTIAL capture: never instantiate or replay it (ending
+                    # the capture may itself fail once the capture is invalidated)
+                    self.nat.graph_abort()
+                    raise
+                gid, self.graph_nodes = self.nat.graph_end()
+                # nothing has executed so far (a capture records, it does not run): a failing first replay leaves the
+                # update phase undone as well, so the eager path below is the whole phase, not a repeat
+                self.nat.graph_launch(gid)
+            except RuntimeError as e:
                 self._graph_id = None
-                raise
-            self._graph_id, self.graph_nodes = self.nat.graph_end()
-            self.nat.graph_launch(self._graph_id)
-            self.adam_step += self._graph_steps
-            return
+                if not parallel.active():
+                    raise                                        # single process: the error surfaces as before
+                # env-sharded run: collectives inside a graph are the one thing a one-GPU box cannot prove.  Fall back
+                # to eager launches (same launches, same order, same collectives: peers that did capture stay in step)
+                self.graph_update = False
+                self.graph_fallback = f"{type(e).__name__}: {e}"
+                import sys
+                print(f"[catppo] rank {self.rank}: hipGraph capture / first replay of the update phase failed, "
+                      f"falling back to eager launches: {self.graph_fallback}", file=sys.stderr)
+            else:
+                self._graph_id = gid
+                self.adam_step += self._graph_steps
+                return
         self.adam_step += self._update_body(perms)
 
     # ------------------------------------------------------------------ one iteration

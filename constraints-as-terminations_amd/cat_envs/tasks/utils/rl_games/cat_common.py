@@ -149,9 +149,14 @@ class CaTA2CAgent:
         """{"actions", "values" (N,1), "neglogpacs" (N,), "mus", "sigmas"} from the HIP policy"""
         a = self.agent
         x = obs["obs"]
-        action, logp, _, value = a.get_action_and_value(x)
-        mu, _, _, _ = a.get_action_and_value(x, deterministic=True)
-        sig = torch.exp(a.actor_logstd.detach()).expand_as(mu)
+        # ONE forward per env step: the noise is drawn here, so the mean follows from the sample the head kernel made,
+        # mu = a - sigma * eps (within one rounding of |a| of the kernel's own mu; rl_games only feeds "mus" to its KL
+        # estimate).  A second, deterministic forward just to read mu doubled the rollout's forward cost.
+        n = x.reshape(-1, a.obs_dim).shape[0]
+        eps = torch.randn(n, a.act_dim, device=x.device)
+        action, logp, _, value = a.get_action_and_value(x, eps=eps)
+        sig = torch.exp(a.actor_logstd.detach()).expand_as(action)
+        mu = action - sig * eps
         return {"actions": action, "values": value, "neglogpacs": -logp, "mus": mu, "sigmas": sig}
 
     def get_values(self, obs):

@@ -23,6 +23,8 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   char why[256] = {0};
 };
@@ -54,8 +56,11 @@ RcclApi* rccl() {
   api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
   api.Broadcast = reinterpret_cast<decltype(api.Broadcast)>(sym("ncclBroadcast"));
   api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
   api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.Broadcast || !api.AllGather) {
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.Broadcast || !api.AllGather ||
+      !api.GroupStart || !api.GroupEnd) {
     snprintf(api.why, sizeof(api.why), "librccl is missing an entry point");
     dlclose(h);
     return nullptr;
@@ -167,4 +172,42 @@ extern "C" int catppo_allgather(catppo_ctx* ctx, const void* send, void* recv, i
                                        static_cast<hipStream_t>(stream));
   if (rc != ncclSuccess) return comm_fail(ctx, r, "ncclAllGather", rc);
   return CATPPO_OK;
+}
+
+// ---- gradient buckets (ABI 0.4) ------------------------------------------------------------------------------------
+// The reference's distributed front end reduces every gradient after backward() (skrl/ppo.py:534-537).  Here the flat
+// gradient is reduced in per-layer buckets on the context's side stream while the backward launches of the layers
+// below still run (catppo_ppo_minibatch_grad*, see mlp.hip): the ranges of one bucket go out as ONE grouped operation.
+int catppo_internal_allreduce_ranges(catppo_ctx* ctx, float* base, const int64_t* off, const int64_t* cnt, int n,
+                                     hipStream_t stream) {
+  if (!ctx->comm) return catppo_fail(ctx, CATPPO_E_COMM, "gradient bucket all-reduce: no communicator");
+  RcclApi* r = rccl();
+  ncclResult_t rc = n > 1 ? r->GroupStart() : ncclSuccess;
+  if (rc != ncclSuccess) return comm_fail(ctx, r, "ncclGroupStart", rc);
+  ncclResult_t first_bad = ncclSuccess;
+  for (int i = 0; i < n; ++i) {
+    if (cnt[i] <= 0) continue;
+    rc = r->AllReduce(base + off[i], base + off[i], (size_t)cnt[i], ncclFloat32, ncclSum,
+                      static_cast<ncclComm_t>(ctx->comm), stream);
+    if (rc != ncclSuccess && first_bad == ncclSuccess) first_bad = rc;
+  }
+  if (n > 1) {
+    rc = r->GroupEnd();      // always closed, also after a failed member call
+    if (rc != ncclSuccess && first_bad == ncclSuccess) first_bad = rc;
+  }
+  if (first_bad != ncclSuccess) return comm_fail(ctx, r, "ncclAllReduce (gradient bucket)", first_bad);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_set_grad_overlap(catppo_ctx* ctx, int on) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, on == 0 || on == 1);
+  if (on && ctx->use_side)
+    return catppo_fail(ctx, CATPPO_E_ARG, "catppo_set_grad_overlap: the side stream is taken by CATPPO_SIDE_STREAM=1");
+  ctx->grad_overlap = on != 0;
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_grad_overlap_active(catppo_ctx* ctx) {
+  return (ctx && ctx->grad_overlap && ctx->comm != nullptr) ? 1 : 0;
 }

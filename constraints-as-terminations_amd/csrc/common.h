@@ -28,6 +28,9 @@ struct catppo_ctx {
   // RCCL communicator (comm.hip; librccl is dlopen'ed on first use)
   void* comm = nullptr;      // ncclComm_t
   int comm_rank = 0, comm_world = 0;
+  // catppo_set_grad_overlap: the gradient all-reduce of an optimiser step runs per layer bucket on the side stream,
+  // under the backward launches of the layers below (effective only while a communicator exists)
+  bool grad_overlap = false;
   // device-side completion tickets of the "last workgroup folds" kernels (zero between launches)
   unsigned int* tickets = nullptr;   // [kTickets]
   static constexpr int kTickets = 64;
@@ -88,6 +91,10 @@ int catppo_internal_launch_terms(catppo_ctx* ctx, const catppo_term_desc* desc, 
                                  const float* forces, int64_t forces_env_stride, int H, int B, const float* command,
                                  int command_ld, float* cstr, int K, float* colmax_partial, int* nblk_out,
                                  hipStream_t stream);
+
+// comm.hip: SUM all-reduce of n ranges [off[i], off[i] + cnt[i]) of one fp32 buffer as ONE grouped RCCL operation on `stream`
+int catppo_internal_allreduce_ranges(catppo_ctx* ctx, float* base, const int64_t* off, const int64_t* cnt, int n,
+                                     hipStream_t stream);
 
 // NaN-propagating max (torch.max semantics): once NaN, stays NaN
 __device__ __forceinline__ float nanmax(float m, float x) { return (x > m || x != x) ? x : m; }

@@ -1804,6 +1804,17 @@ bool fused_fwd_plan(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, int6
   for (int net = 0; net < 2; ++net)
     for (int l = 0; l <= nl; ++l) fa->off_w[net][l] = L.off_w[net][l], fa->off_b[net][l] = L.off_b[net][l];
   *lds = sizeof(float) * ((size_t)kFR * (fa->ld0 + fa->ld1) + kFRing);
+  // fused_chunk's pipeline deliberately runs past the end of a contraction: its last iterations stage up to three 16-k
+  // weight slabs beyond the last row of a chunk (never multiplied) and read A fragments past K in the LDS tile.  Both
+  // are in bounds only because of how the buffers are laid out - checked here instead of assumed: (1) every hidden
+  // weight matrix is followed by at least 64 more floats of the flat parameter buffer (its bias, the next layer),
+  // (2) the two activation tiles are followed by the weight rings inside the same dynamic-LDS allocation (act0's
+  // overrun lands in act1, act1's in the rings: >= 64 floats each).  A layout that breaks either takes the layer-wise path.
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < nl; ++l)
+      if (L.off_w[net][l] + (int64_t)sh->hidden[l] * L.in_dim[l] + 64 > L.n_flat) return false;
+  static_assert(kFRing >= 64, "the weight rings double as the over-read margin of the activation tiles");
+  if ((size_t)kFR * fa->ld1 < 64) return false;
   return *lds <= 160 * 1024;
 }
 
@@ -2111,6 +2122,9 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   // CATPPO_SIDE_STREAM=1 (measured slower, kept for A/B): the weight gradients are forked to the context's side
   // stream as soon as a layer's dZ exists and joined before returning to the caller's stream order.
   const bool fork = ctx->use_side;
+  // catppo_set_grad_overlap + a communicator: fold and all-reduce the gradient in per-layer buckets on the side stream
+  // while the backward launches of the layers below run on `s` (see the end of the layer loop)
+  const bool overlap = !fork && ctx->grad_overlap && ctx->comm != nullptr;
   const int bf16 = shape->mfma_bf16;   // 0 fp32 MFMA, 1 bf16 operands, 2 split-bf16 (bf16x3)
   hipStream_t side = fork ? ctx->side : s;
 #define CATPPO_HIP_OK(call)                                                                          \
@@ -2208,6 +2222,35 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         launch_gemm_auto<true, false, gemm::EPI_MUL_DELU>(px, s, bf16);
       CATPPO_CHECK_LAUNCH(ctx);
     }
+    if (overlap) {
+      // Bucket l = {W_l, b_l of both networks} (+ heads and log-std with the last hidden layer): its partials are
+      // complete once the launch above is done, so its fold and its all-reduce go to the side stream NOW and run under
+      // the launches of layers l-1 .. 0.  Per element the sums are those of the single fold launch (seg_reduce treats
+      // every segment independently), the ranges of a bucket are contiguous per network in the flat layout
+      // (W_l | b_l | W_l+1 ...) and travel as one grouped RCCL operation.
+      CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
+      CATPPO_HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork[l], 0));
+      hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, ctx->side, segs, hp->ent_coef,
+                         hp->vf_coef);
+      CATPPO_CHECK_LAUNCH(ctx);
+      segs.n = 0;
+      int64_t off[3], cnt[3];
+      int nr = 0;
+      const bool last = l == nl - 1;
+      for (int net = 0; net < 2; ++net) {
+        // end of this network's (W_l, b_l) = start of its next layer; the bucket of the last hidden layer runs on
+        // through the head layer to the end of the network's block
+        const int64_t end = last ? (net == 0 ? L.off_w[1][0] : L.n_flat) : L.off_w[net][l + 1];
+        off[nr] = L.off_w[net][l], cnt[nr] = end - L.off_w[net][l], ++nr;
+      }
+      if (last) off[nr] = L.off_logstd, cnt[nr] = L.off_w[0][0] - L.off_logstd, ++nr;
+      if (int rc = catppo_internal_allreduce_ranges(ctx, grad, off, cnt, nr, ctx->side)) return rc;
+    }
+  }
+  if (overlap) {      // every bucket is folded and reduced on the side stream: join
+    CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
+    CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    return CATPPO_OK;
   }
   // every split-K / head partial of the minibatch is folded into the flat gradient by one launch
   hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);

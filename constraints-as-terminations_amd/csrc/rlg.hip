@@ -11,6 +11,7 @@
 // (running means over the last `max_size` finished episodes; rl_games is not vendored - its published update rule is
 // restated in catppo.h, PARITY UNPINNED against rl_games itself) live in device memory (catppo_rlg_meters).
 #include "common.h"
+#include "xwg.h"
 
 namespace {
 
@@ -38,7 +39,6 @@ __global__ __launch_bounds__(256) void rlg_episode_step_kernel(const float* __re
                                                                uint8_t* __restrict__ done_mask) {
   constexpr int NS = 2 + 2 * kMaxV;                  // count, sum len, sum rew[V], sum shaped[V]
   __shared__ double sm[4][NS];
-  __shared__ bool last;
   double acc[NS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) acc[q] = 0.0;
@@ -68,22 +68,17 @@ __global__ __launch_bounds__(256) void rlg_episode_step_kernel(const float* __re
   __syncthreads();
   if (threadIdx.x < NS) {
     const int q = threadIdx.x;
-    __hip_atomic_store(part + (int64_t)blockIdx.x * NS + q, (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xwg_store(part + (int64_t)blockIdx.x * NS + q, (sm[0][q] + sm[1][q]) + (sm[2][q] + sm[3][q]));
   }
-  // last workgroup to arrive folds the partials in block order (result independent of arrival order).  No device-scope
-  // fences (an L2 write-back / invalidate per workgroup on gfx950, see rollout.hip): the partial rows are device-scope
-  // atomic stores, complete before the arrive, and read back with device-scope atomic loads.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!last) return;
+  // last workgroup to arrive folds the partials in block order (result independent of arrival order).  The hand-shake
+  // is xwg.h's (shared with rollout.hip): device-scope atomic stores / loads ordered by the stores' completion instead
+  // of device-scope fences (an L2 write-back / invalidate per workgroup on gfx950); -DROLLOUT_FENCES=1 builds the fence
+  // version here too.  (last_block_arrives re-arms the ticket for the next launch.)
+  if (!last_block_arrives(ticket, gridDim.x)) return;
   if (threadIdx.x < NS) {
     const int q = threadIdx.x;
     double s = 0.0;
-    for (unsigned b = 0; b < gridDim.x; ++b)
-      s += __hip_atomic_load(part + (int64_t)b * NS + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (unsigned b = 0; b < gridDim.x; ++b) s += xwg_load(part + (int64_t)b * NS + q);
     sm[0][q] = s;
   }
   __syncthreads();
@@ -100,7 +95,6 @@ __global__ __launch_bounds__(256) void rlg_episode_step_kernel(const float* __re
       c1 = a, c2 = b;
     }
     meters->size_rewards = c1, meters->size_shaped = c2;
-    *ticket = 0;
   }
 }
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CATPPO_VERSION 300 /* 0.3.0 */
+#define CATPPO_VERSION 400 /* 0.4.0 */
 
 #define CATPPO_OK 0
 #define CATPPO_E_ARG (-1)     /* bad argument */
@@ -580,6 +580,18 @@ int catppo_allreduce(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int o
 int catppo_broadcast(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int root, void* stream);
 /* recv[rank * bytes ...] = send of that rank, for every rank (ncclAllGather of raw bytes; send != recv) */
 int catppo_allgather(catppo_ctx* ctx, const void* send, void* recv, int64_t bytes, void* stream);
+
+/* ---- ABI 0.4: gradient all-reduce in per-layer buckets, overlapped with the backward pass ------------------------
+ * semantics replaced: skrl/ppo.py:534-537 (every gradient reduced after backward()).  With the switch on AND a
+ * communicator present, catppo_ppo_minibatch_grad / _packed fold the partials of hidden layer l (and, with the last
+ * hidden layer, the heads and log-std) as soon as that layer's weight-gradient launch is enqueued - on the context's
+ * side stream - and SUM-all-reduce that bucket of the flat gradient there, while the launches of the layers below
+ * still run on `stream`; the side stream joins `stream` before the call returns its stream order, so `grad` is the
+ * GLOBAL sum when the next operation on `stream` (catppo_clip_adam*) reads it and the caller must NOT all-reduce it
+ * again.  Sums per element are those of the single fold launch (bit-identical on a world of one); the whole sequence
+ * is capturable.  catppo_grad_overlap_active: 1 when the next gradient call will reduce its own buckets. */
+int catppo_set_grad_overlap(catppo_ctx* ctx, int on);
+int catppo_grad_overlap_active(catppo_ctx* ctx);
 
 #ifdef __cplusplus
 }

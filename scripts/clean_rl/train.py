@@ -67,8 +67,17 @@ def main(argv=None):
     args_cli, hydra_args = build_parser().parse_known_args(argv)
     if args_cli.video:
         args_cli.enable_cameras = True
-    # clear out sys.argv for the override resolver, like the reference does for Hydra (train.py:57-58)
+    # clear out sys.argv for the override resolver, like the reference does for Hydra (train.py:57-58); an in-process
+    # caller (tests, notebooks) gets its own argv back when main returns
+    argv_before = sys.argv
     sys.argv = [sys.argv[0]] + hydra_args
+    try:
+        return _main(args_cli)
+    finally:
+        sys.argv = argv_before
+
+
+def _main(args_cli):
     import torch
 
     import cat_envs.tasks  # noqa: F401  registers the tasks

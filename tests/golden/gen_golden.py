@@ -37,8 +37,12 @@ torch.set_num_threads(1)      # deterministic reductions for the frozen vectors
 torch.use_deterministic_algorithms(True)
 
 
+#: where save() writes: next to this file, or a scratch directory under ``--check``
+OUT_DIR = HERE
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
     print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -554,8 +558,43 @@ def gen_rlg_play_steps():
     save("rlg_play_steps", **out)
 
 
+def check_against_committed(scratch):
+    """every fixture regenerated into ``scratch`` equals the committed one array for array (same keys, dtypes, shapes,
+    bits): the committed vectors ARE what the reference computes here.  Returns the list of mismatches."""
+    bad = []
+    committed = sorted(f for f in os.listdir(HERE) if f.endswith(".npz"))
+    fresh = sorted(f for f in os.listdir(scratch) if f.endswith(".npz"))
+    if committed != fresh:
+        bad.append(f"fixture sets differ: committed {committed} vs regenerated {fresh}")
+    for f in sorted(set(committed) & set(fresh)):
+        a, b = np.load(os.path.join(HERE, f), allow_pickle=False), np.load(os.path.join(scratch, f), allow_pickle=False)
+        if sorted(a.files) != sorted(b.files):
+            bad.append(f"{f}: keys differ: {sorted(set(a.files) ^ set(b.files))}")
+            continue
+        for k in a.files:
+            x, y = a[k], b[k]
+            same = x.dtype == y.dtype and x.shape == y.shape and \
+                (np.array_equal(x, y, equal_nan=True) if x.dtype.kind in "fc" else np.array_equal(x, y))
+            if not same:
+                bad.append(f"{f}[{k}]: {x.dtype}{x.shape} vs {y.dtype}{y.shape}")
+    return bad
+
+
 def main():
     assert R.have_reference(), "needs /root/reference (build container only)"
+    if sys.argv[1:2] == ["--check"]:      # regenerate everything into a scratch directory and compare with the committed files
+        import tempfile
+        global OUT_DIR
+        with tempfile.TemporaryDirectory() as tmp:
+            OUT_DIR = sys.argv[2] if len(sys.argv) > 2 else tmp
+            os.makedirs(OUT_DIR, exist_ok=True)
+            sys.argv[1:] = []
+            main()
+            bad = check_against_committed(OUT_DIR)
+        for b in bad:
+            print("MISMATCH", b)
+        print(f"golden --check: {len(bad)} mismatches")
+        sys.exit(1 if bad else 0)
     if sys.argv[1:] == ["skrl_gae"]:      # regenerate one fixture without touching the others
         return gen_skrl_gae()
     if sys.argv[1:] == ["rlg_play_steps"]:

@@ -1,0 +1,63 @@
+"""bench.py starts its own ranks: `python bench.py --gpus N` with no launcher around it must run N
+ranks and print ONE line with n_gpus == N; a launcher that started a different number of ranks is refused.
+
+Reference precedent for a self-contained distributed entry point: scripts/skrl/train.py:28-30,116-117,
+scripts/rl_games/train.py:23-25,100-107 (`--distributed` flags, no wrapper script needed)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR",
+                                                            "MASTER_PORT", "CATPPO_FORCE_DIST")}
+    env.update(kw)
+    return env
+
+
+def test_print_launch_is_the_drivers_command_line():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "3", "--warmup", "1", "--print-launch"],
+                       capture_output=True, text=True, env=_env(), timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = r.stdout.strip().splitlines()[-1]
+    for tok in ("-m torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr 127.0.0.1",
+                "bench.py --gpus 4 --steps 3 --warmup 1"):
+        assert tok in line, (tok, line)
+    assert "--print-launch" not in line
+
+
+def test_world_size_that_differs_from_gpus_is_refused():
+    """no JSON line whose n_gpus differs from --gpus: a launcher that started 2 ranks for `--gpus 1` gets exit code 2"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1"], capture_output=True, text=True, timeout=300,
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode == 2
+    assert r.stdout.strip() == "" and "refusing to run" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
+    """the launcher proven on whatever box this runs on: with fewer than two GPUs the two ranks share cuda:0 and exchange
+    through gloo with host staging (the transport of test_gpu_two_rank_trainer.py); with two or more they use RCCL"""
+    import torch
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=_env(), timeout=1500, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["self_launched"] is True
+    assert d["config"]["envs_total"] == 2 * d["config"]["envs_per_gpu"] and d["scaling"] == "weak"
+    assert d["comm_ms_per_iteration"] > 0 and d["comm"]["collectives_per_iteration"] >= 24 + 30
+    if torch.cuda.device_count() < 2:
+        assert d["ranks_share_gpus"] is True and d["physical_gpus"] == 1
+        assert "gloo" in d["config"]["collectives"] and d["config"]["rccl_world"] == 0
+    else:
+        assert d["ranks_share_gpus"] is False and d["config"]["rccl_world"] == 2
+        assert d["config"]["graph_fallback"] is None or isinstance(d["config"]["graph_fallback"], str)
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["envs_total"] * 24 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]

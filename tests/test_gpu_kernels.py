@@ -213,6 +213,19 @@ def test_constraint_terms_vs_reference_golden(nat, golden):
         exp = np.asarray(g[name]).astype(np.float32).reshape(n, -1)
         if name in loose:
             np.testing.assert_allclose(got, exp, rtol=1e-6, atol=1e-5, err_msg=name)
+            # the CaT mask is bit-exact GIVEN the constraint stream; a norm that differs from the reference's by one ulp
+            # flips `c > 0` only at c == 0, so the violation masks of the two norm-based terms (cat/constraints.py:113-119,
+            # 201-211) must agree element for element, and the number of last-bit differences is put on record
+            np.testing.assert_array_equal(got > 0, exp > 0, err_msg=name + ": sign of the constraint (violation mask)")
+            ulp = np.abs(got.view(np.int32).astype(np.int64) - exp.view(np.int32).astype(np.int64))
+            same_sign = np.signbit(got) == np.signbit(exp)
+            assert ulp[same_sign].max(initial=0) <= 2, (name, int(ulp[same_sign].max()))
+            import parity_record
+            parity_record.record("terms_" + name + "_vs_reference_golden",
+                                 {"elements": int(got.size), "not_bit_equal": int((got != exp).sum()),
+                                  "max_ulp": int(ulp[same_sign].max(initial=0)),
+                                  "sign_disagreements": int(((got > 0) != (exp > 0)).sum())},
+                                 sizes=dict(n_envs=n, width=int(t.width)), seed=int(g["seed"]))
         else:
             np.testing.assert_array_equal(got, exp, err_msg=name)
 

@@ -1,0 +1,157 @@
+"""Round-4 GPU tests: the deployment forward on the device against the reference's own output, gradient buckets reduced
+beside the backward pass (ABI 0.4), the reported eager fallback of a failed graph capture."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import streams as S
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_agent_forward_on_the_device_vs_reference_golden(golden):
+    """``Agent.forward(x)`` = observation normaliser (update=False) + deterministic mean (reference cleanrl/ppo.py:121-123,
+    what scripts/clean_rl/play.py:140-144 calls), on the device, against ``agent.npz["deterministic"]`` - the reference
+    ``Agent`` itself on these weights / inputs / normaliser state (gen_golden.gen_agent)."""
+    from cat_envs.tasks.utils.cleanrl.ppo import Agent
+    g = golden("agent")
+    d, a = int(g["obs_dim"]), int(g["act_dim"])
+
+    class _Space:
+        def __init__(self, shape):
+            self.shape = shape
+
+    class _Env:
+        num_envs = 96
+        single_observation_space = {"policy": _Space((d,))}
+        single_action_space = _Space((a,))
+
+        @property
+        def unwrapped(self):
+            return self
+
+    ag = Agent(_Env()).to("cuda")
+    w = S.agent_weights(int(g["weight_seed"]), d, a)
+    sd = ag.state_dict()
+    ag.load_state_dict({k: (torch.from_numpy(w[k]) if k in w else v) for k, v in sd.items()})
+    rs = np.random.RandomState(int(g["input_seed"]))
+    x = rs.standard_normal((96, d)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    ag.obs_rms(torch.from_numpy(x * 2 + 1).cuda())          # the golden run moved the normaliser off identity the same way
+    got = ag(xd)                                            # forward(): deterministic=True
+    assert got.shape == (96, a)
+    err = float(np.abs(got.cpu().numpy().astype(np.float64) - g["deterministic"]).max())
+    import parity_record
+    parity_record.record("agent_forward_deterministic_vs_reference_golden", {"actions": err},
+                         sizes=dict(rows=96, obs_dim=d), seed=int(g["input_seed"]))
+    assert err <= 1e-5, err                                 # north_star's fp32 bar
+    # the normaliser was NOT updated by forward()
+    cnt = float(ag.obs_rms.count)
+    ag(xd)
+    assert float(ag.obs_rms.count) == cnt == 97.0
+
+
+_OVERLAP_CODE = r"""
+import os, sys, torch, numpy as np
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['TEST_PORT'], RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', 0))
+import smoke_impl
+from cat_envs import parallel
+from cat_envs.shim import make
+from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+assert parallel.active()
+res = {}
+for tag, over in (("off_eager", dict(grad_overlap=False, graph_update=False)),
+                  ("on_eager", dict(grad_overlap=True, graph_update=False)),
+                  ("on_graph", dict(grad_overlap=True, graph_update=True))):
+    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(512, 8, 1024, 2, 50, (256, 256, 256), True, obs_dim=48, seed=7)
+    for k, v in over.items():
+        setattr(agent_cfg, k, v)
+    torch.manual_seed(3)
+    tr = PPOTrainer(make(task, cfg=env_cfg), agent_cfg)
+    assert parallel.native_comm_active() and tr.nat.comm_world == 1
+    assert tr.grad_overlap == over["grad_overlap"] == tr.nat.grad_overlap_active, (tag, tr.grad_overlap)
+    for _ in range(3):
+        tr.run_iteration(log=False)
+    torch.cuda.synchronize()
+    assert tr.graph_update == over["graph_update"] and tr.graph_fallback is None
+    res[tag] = (tr.agent.flat.cpu().numpy().copy(), tr.exp_avg_sq.cpu().numpy().copy(), tr.diag.cpu().numpy().copy(),
+                tr.graph_nodes)
+for tag in ("on_eager", "on_graph"):
+    for i in range(3):
+        np.testing.assert_array_equal(res[tag][i], res["off_eager"][i], err_msg=f"{tag}[{i}]")
+assert np.abs(res["off_eager"][0]).sum() > 0 and res["on_graph"][3] > 0
+parallel.shutdown_native_comm()
+torch.distributed.destroy_process_group()
+print("OVERLAP-OK", res["on_graph"][3])
+"""
+
+
+def _run_code(code, **env_extra):
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, CATPPO_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TEST_PORT=str(port),
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "constraints-as-terminations_amd")]), **env_extra)
+    return subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+
+
+def test_gradient_buckets_reduced_beside_the_backward_pass_world_of_one():
+    """catppo_set_grad_overlap (ABI 0.4): per-layer fold + grouped RCCL all-reduce on the side stream inside
+    catppo_ppo_minibatch_grad_packed, eager and captured in the update-phase graph, on a world of one (all a one-GPU box
+    has): parameters, Adam state and diagnostics BIT-identical to the single fold launch + one all-reduce."""
+    r = _run_code(_OVERLAP_CODE)
+    assert r.returncode == 0 and "OVERLAP-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_FALLBACK_CODE = r"""
+import os, sys, torch, numpy as np
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['TEST_PORT'], RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', 0))
+import smoke_impl
+from cat_envs import parallel
+from cat_envs.shim import make
+from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+out = []
+for broken in (False, True):
+    task, env_cfg, agent_cfg = smoke_impl.make_cfgs(256, 8, 512, 2, 50, (256, 256, 256), True, obs_dim=48, seed=7)
+    agent_cfg.graph_update = True
+    torch.manual_seed(3)
+    tr = PPOTrainer(make(task, cfg=env_cfg), agent_cfg)
+    if broken:                # the first replay fails (as an unsupported capture on some node would): eager from then on
+        real = tr.nat.graph_launch
+        def bad_launch(gid):
+            raise RuntimeError("libcatppo error -2: catppo_graph_launch: injected failure")
+        tr.nat.graph_launch = bad_launch
+    for _ in range(3):
+        tr.run_iteration(log=False)
+    torch.cuda.synchronize()
+    if broken:
+        tr.nat.graph_launch = real
+        assert tr.graph_update is False and "injected failure" in tr.graph_fallback, tr.graph_fallback
+    else:
+        assert tr.graph_update is True and tr.graph_fallback is None
+    assert tr.adam_step == 3 * 2 * 4, tr.adam_step
+    out.append(tr.agent.flat.cpu().numpy().copy())
+np.testing.assert_array_equal(out[0], out[1])
+parallel.shutdown_native_comm()
+torch.distributed.destroy_process_group()
+print("FALLBACK-OK")
+"""
+
+
+def test_failed_graph_replay_falls_back_to_eager_launches_and_says_so():
+    """graph replay with RCCL inside is the default at every world size; when the capture or
+    the first replay fails in an env-sharded run the update phase continues eagerly (bit-identical result) and the
+    reason is kept in ``PPOTrainer.graph_fallback`` (bench.py prints it)."""
+    r = _run_code(_FALLBACK_CODE)
+    assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "falling back to eager launches" in r.stderr

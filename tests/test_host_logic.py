@@ -154,6 +154,9 @@ def test_cli_surface(tmp_path):
         sys.argv = ["train.py", "agnt.minibatch_size=512"]
         with pytest.raises(KeyError, match="agnt"):
             body(None)
+        # a stray token (the value of an unknown `--flag value` pair left by parse_known_args) is reported, not fatal
+        sys.argv = ["train.py", "--some_unknown_flag", "7", "agent.minibatch_size=256"]
+        body(None)           # must not raise
     finally:
         sys.argv = argv0
     # checkpoint discovery: latest run, highest iteration (reference naming model_<it>.pt)
