@@ -514,6 +514,7 @@ struct FusedFwdArgs {
   int rng_step;
   float* eps_out;
   int do_head;
+  int nets_per_wg;                 // rows_fwd_kernel: 2 = one workgroup walks both networks (grid.y == 1), 1 = grid.y == nets
 };
 
 // Heads of the fused forward on the 32-row tile in LDS.  head_act_kernel gives every row a whole wave (the launch has
@@ -853,6 +854,80 @@ __global__ __launch_bounds__(kFT) void fused_fwd_kernel(const FusedFwdArgs a) {
     default: break;
   }
   FF_TL(8);
+}
+
+// ------------------------------------------------------------------------------- row-resident forward (round 4)
+// fwd_rows.h: R rows of activations stay in ONE LDS tile from layer to layer (in place), weights stream through
+// wave-private rings in full 128-byte lines.  R = 64: the hidden layers below the last one of a training minibatch
+// (activations also stored for the backward; the last layer + heads stay with fwd_head_kernel).  R = 32: the whole
+// rollout forward incl. heads (same role as fused_fwd_kernel).  Every layer handled here is 256 wide.
+#include "fwd_rows.h"
+
+template <int R>
+__global__ __launch_bounds__(rowsfwd::kThreads) void rows_fwd_kernel(const FusedFwdArgs a) {
+  using gemm::f32x16;
+  constexpr int T = R / 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tile = smem;                                         // [R][ld]
+  const int ld = a.ld0;
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* wring = smem + R * ld + wave * rowsfwd::kRingWave;    // this wave's two weight slots
+  const int64_t r0 = (int64_t)blockIdx.x * R;
+  const int nets_here = a.nets_per_wg;
+  rowsfwd::Layer<R> ly;
+  for (int ni = 0; ni < nets_here; ++ni) {
+    const int net = a.net0 + (nets_here == 2 ? ni : (int)blockIdx.y);
+    const int slot_net = nets_here == 2 ? ni : (int)blockIdx.y;      // index into a.Hout
+    // first weight slab of layer 0: requested before the observation tile so that both round trips overlap
+    ly.stage_first(a.params + a.off_w[net][0], a.Dp, wave, lane);
+    if (ni > 0) __syncthreads();                              // the previous network's last tile is still being stored
+    {
+      const int q4 = a.Dp / 4;
+      for (int f = tid; f < R * q4; f += rowsfwd::kThreads) {
+        const int r = f / q4, q = f - r * q4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past M: zeros, never stored
+        if (r0 + r < a.M) v = *reinterpret_cast<const float4*>(a.x + (r0 + r) * a.Dp + 4 * q);
+        *reinterpret_cast<float4*>(tile + r * ld + 4 * q) = v;
+      }
+    }
+    __syncthreads();
+    int K = a.Dp;
+    for (int l = 0; l < a.n_hidden; ++l) {
+      f32x16 acc[T];
+      ly.run(tile, ld, wring, K, acc, lane);
+      const float bias = a.params[a.off_b[net][l] + wave * 32 + l31];
+      // the next contraction's first weights: layer l+1 of this network, or layer 0 of the next one
+      if (l + 1 < a.n_hidden) ly.stage_first(a.params + a.off_w[net][l + 1], rowsfwd::kWidth, wave, lane);
+      __syncthreads();                                        // every wave is done reading the tile: overwrite it
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+          tile[row * ld + wave * 32 + l31] = gemm::elu_f(acc[t][r] + bias);
+        }
+      __syncthreads();
+      float* hg = a.Hout[slot_net][l];
+      if (hg != nullptr) {       // training: the activations also go to memory, under the next layer's contraction
+        constexpr int Q4 = rowsfwd::kWidth / 4;
+#pragma unroll 4
+        for (int f = tid; f < R * Q4; f += rowsfwd::kThreads) {
+          const int r = f / Q4, q = f - r * Q4;
+          if (r0 + r < a.M) {
+            const float4 v = *reinterpret_cast<const float4*>(tile + r * ld + 4 * q);
+            const float o[4] = {v.x, v.y, v.z, v.w};
+            store_vec_wt<4>(hg + (r0 + r) * rowsfwd::kWidth + 4 * q, o);
+          }
+        }
+      }
+      K = rowsfwd::kWidth;
+    }
+    if (a.do_head) {             // rollout: heads on the tile (the rings are free: head weights go there)
+      __syncthreads();
+      fused_head<rowsfwd::kWidth>(a, tile, ld, net, r0, smem + R * ld);
+    }
+  }
 }
 
 #ifdef FUSED_TL
@@ -1818,6 +1893,43 @@ bool fused_fwd_plan(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, int6
   return *lds <= 160 * 1024;
 }
 
+// rows_fwd_kernel<R> applies when: fp32 MFMA, every layer it computes is 256 wide (eight waves x 32 columns, outputs of a
+// layer held in accumulators until the tile may be overwritten), the tile + rings fit the LDS.  `n_layers` hidden layers
+// are computed (training: all but the last; rollout: all).
+bool rows_fwd_plan(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, int n_layers, int R, FusedFwdArgs* fa,
+                   size_t* lds) {
+  if (sh->mfma_bf16 != 0 || n_layers < 1 || n_layers > sh->n_hidden) return false;
+  for (int l = 0; l < n_layers; ++l)
+    if (sh->hidden[l] != rowsfwd::kWidth) return false;
+  const int wmax = L.obs_pad > rowsfwd::kWidth ? L.obs_pad : rowsfwd::kWidth;
+  fa->Dp = L.obs_pad, fa->n_hidden = n_layers;
+  fa->ld0 = wmax + 4, fa->ld1 = 0;            // (w + 4) / 4 odd: 16 rows of a b128 read hit 16 distinct 4-bank slots
+  for (int l = 0; l < n_layers; ++l) fa->hidden[l] = sh->hidden[l];
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l <= sh->n_hidden; ++l) fa->off_w[net][l] = L.off_w[net][l], fa->off_b[net][l] = L.off_b[net][l];
+  // a 48-wide first layer reads its second 32-k slab 16 floats past every weight row: the last row's over-read must
+  // stay inside the flat buffer (it lands in the bias that follows)
+  // and the run-ahead request of a slab past the last one reads up to 64 floats past every weight matrix
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < n_layers; ++l)
+      if (L.off_w[net][l] + (int64_t)sh->hidden[l] * L.in_dim[l] + 96 > L.n_flat) return false;
+  *lds = R == 64 ? rowsfwd::lds_bytes<64>(fa->ld0) : rowsfwd::lds_bytes<32>(fa->ld0);
+  return *lds <= 160 * 1024;
+}
+
+template <int R>
+void rows_fwd_launch(const FusedFwdArgs& fa, size_t lds, int64_t rows, int nets, int n_cu, hipStream_t s) {
+  FusedFwdArgs a = fa;
+  const int64_t tiles = cdiv64(rows, R);
+  // enough row tiles to fill the chip: one workgroup walks both networks (one round of workgroups, the observation
+  // tile of a row block fetched by one CU); fewer: one workgroup per (tile, network)
+  a.nets_per_wg = (nets == 2 && tiles >= n_cu) ? 2 : 1;
+  auto kern = rows_fwd_kernel<R>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, a.nets_per_wg == 2 ? 1 : nets), dim3(rowsfwd::kThreads), lds, s, a);
+}
+
 // rollout policy step shared by catppo_policy_act / _ex / _rng and catppo_value / _ex
 int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
                 const float* eps, const float* given_action, float* action, float* logprob, void* value,
@@ -1829,6 +1941,24 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
   CATPPO_CHECK_ARG(ctx, params && x && value && (critic_only || (action && logprob)));
   CATPPO_CHECK_ARG(ctx, value_dtype == CATPPO_F32 || value_dtype == CATPPO_F16);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    // row-resident forward with full-line weight loads (round 4), same window as fused_fwd_kernel; CATPPO_ROWS_FWD_ROLLOUT
+    // selects it (A/B against fused_fwd_kernel)
+    static const int rows_rollout = env_int("CATPPO_ROWS_FWD_ROLLOUT", 0);
+    static const int rr_max = env_int("CATPPO_FUSED_FWD_MAX_ROWS", 4096), rr_min = env_int("CATPPO_FUSED_FWD_MIN_ROWS", 2049);
+    FusedFwdArgs ra{};
+    size_t rlds = 0;
+    if (rows_rollout && N <= rr_max && N >= rr_min && rows_fwd_plan(shape, L, shape->n_hidden, 32, &ra, &rlds)) {
+      ra.x = x, ra.params = params, ra.M = N;
+      ra.net0 = 0;
+      ra.logstd = params + L.off_logstd, ra.eps = eps, ra.given = given_action, ra.A = shape->act_dim;
+      ra.action = action, ra.logprob = logprob, ra.value_out = value, ra.value_f16 = (int)(value_dtype == CATPPO_F16);
+      ra.rng_state = rng_state, ra.rng_step = rng_step, ra.eps_out = eps_out, ra.do_head = 1;
+      rows_fwd_launch<32>(ra, rlds, N, critic_only ? 1 : 2, 1 << 30, s);     // (n_cu huge: always one network per workgroup)
+      CATPPO_CHECK_LAUNCH(ctx);
+      return CATPPO_OK;
+    }
+  }
   {
     FusedFwdArgs fa{};
     size_t lds = 0;
@@ -2028,7 +2158,20 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const bool fused_head = fused_head_env && (HL == 128 || HL == 256) && nl >= 2 &&
                           L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= fused_head_min && A <= 15;
   if (fused_head) {
-    forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
+    // hidden layers below the last: ONE row-resident launch (fwd_rows.h) when they are all 256 wide and the minibatch has
+    // enough 64-row tiles, else the layer-wise GEMM launches.  CATPPO_ROWS_FWD=0 keeps the latter (A/B).
+    static const int rows_fwd_env = env_int("CATPPO_ROWS_FWD", 1);
+    static const int rows_fwd_min = env_int("CATPPO_ROWS_FWD_MIN_ROWS", 8192);
+    FusedFwdArgs ra{};
+    size_t rlds = 0;
+    if (rows_fwd_env && M >= rows_fwd_min && rows_fwd_plan(shape, L, nl - 1, 64, &ra, &rlds)) {
+      ra.x = w.xmb, ra.params = params, ra.M = M, ra.net0 = 0, ra.do_head = 0;
+      for (int net = 0; net < 2; ++net)
+        for (int l = 0; l < nl - 1; ++l) ra.Hout[net][l] = w.H[net][l];
+      rows_fwd_launch<64>(ra, rlds, M, 2, ctx->n_cu, s);
+    } else {
+      forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
+    }
     CATPPO_CHECK_LAUNCH(ctx);
     Params p{};
     p.xcd_legacy = xcd_legacy();
@@ -2228,10 +2371,14 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       // the launches of layers l-1 .. 0.  Per element the sums are those of the single fold launch (seg_reduce treats
       // every segment independently), the ranges of a bucket are contiguous per network in the flat layout
       // (W_l | b_l | W_l+1 ...) and travel as one grouped RCCL operation.
-      CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
-      CATPPO_HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork[l], 0));
-      hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, ctx->side, segs, hp->ent_coef,
-                         hp->vf_coef);
+      // (the first layer's bucket has nothing left to hide behind - its weight gradient is the last GEMM of the step -
+      // so it stays on `s`: one fork / join pair less, measured 24 us per step for three forks on a world of one)
+      hipStream_t bs = l > 0 ? ctx->side : s;
+      if (l > 0) {
+        CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
+        CATPPO_HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork[l], 0));
+      }
+      hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, bs, segs, hp->ent_coef, hp->vf_coef);
       CATPPO_CHECK_LAUNCH(ctx);
       segs.n = 0;
       int64_t off[3], cnt[3];
@@ -2244,14 +2391,14 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         off[nr] = L.off_w[net][l], cnt[nr] = end - L.off_w[net][l], ++nr;
       }
       if (last) off[nr] = L.off_logstd, cnt[nr] = L.off_w[0][0] - L.off_logstd, ++nr;
-      if (int rc = catppo_internal_allreduce_ranges(ctx, grad, off, cnt, nr, ctx->side)) return rc;
+      // join BEFORE the first layer's own all-reduce: every operation on the communicator is then ordered by stream
+      // dependencies (no two of them concurrently in flight on different streams), inside a captured graph too
+      if (l == 0 && nl > 1) CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+      if (int rc = catppo_internal_allreduce_ranges(ctx, grad, off, cnt, nr, bs)) return rc;
+      if (l == 1) CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));   // the last forked bucket
     }
   }
-  if (overlap) {      // every bucket is folded and reduced on the side stream: join
-    CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
-    CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
-    return CATPPO_OK;
-  }
+  if (overlap) return CATPPO_OK;      // `s` has joined the side stream in front of the last bucket
   // every split-K / head partial of the minibatch is folded into the flat gradient by one launch
   hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);
   CATPPO_CHECK_LAUNCH(ctx);

@@ -155,3 +155,53 @@ def test_failed_graph_replay_falls_back_to_eager_launches_and_says_so():
     r = _run_code(_FALLBACK_CODE)
     assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "falling back to eager launches" in r.stderr
+
+
+# ------------------------------------------------------------------------------------------ row-resident forward
+@pytest.mark.parametrize("D,A,hidden,Bsz,M", [
+    (48, 12, (256, 256, 256), 16384, 16384),      # cfg2's minibatch: 256 row tiles, one workgroup walks both networks
+    (48, 12, (256, 256, 256), 8192, 4133),        # ragged, 65 tiles: one workgroup per (tile, network), last tile 37 rows
+    (235, 12, (256, 256, 256), 8192, 8192),       # cfg4: 240-wide padded observations (7.5 slabs of 32)
+    (48, 12, (256, 256), 4160, 4160),             # two hidden layers: only the first one is computed by the new launch
+    (45, 5, (256, 256, 256, 128), 4096, 4096),    # three fused layers below a 128-wide last layer
+])
+def test_row_resident_forward_equals_the_layerwise_launches(tmp_path, D, A, hidden, Bsz, M):
+    """rows_fwd_kernel<64> (fwd_rows.h: the hidden layers below the last one in ONE launch, activation tile resident in
+    LDS, stored for the backward) against the layer-wise GEMM launches it replaces (cleanrl/ppo.py:78-96 forward): the
+    contraction order per element is the same, so activations - and with them the whole minibatch gradient and the
+    diagnostics - must be BIT-identical.  Two processes (the switch is read once per process)."""
+    import test_gpu_kernels as TK
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"rows{flag}.npz")
+        code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=0, out=out)
+        env = dict(os.environ, CATPPO_ROWS_FWD=flag, CATPPO_ROWS_FWD_MIN_ROWS="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.abs(outs[1]["grad"]).max() > 0
+    np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
+    np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
+
+
+def test_row_resident_rollout_forward_equals_the_layerwise_path(tmp_path):
+    """rows_fwd_kernel<32> with heads (CATPPO_ROWS_FWD_ROLLOUT=1) against the layer-wise rollout forward: hidden layers
+    bit-identical by construction, heads sum in another order (2e-6), Philox noise exact."""
+    import test_gpu_kernels as TK
+    cases = {"cfg2": (48, 12, (256, 256, 256), 4096), "ragged": (45, 12, (256, 256, 256), 2049),
+             "tiny": (48, 7, (256, 256), 33), "wide_obs": (235, 12, (256, 256, 256), 300), "one_row": (48, 12, (256,), 1)}
+    outs = []
+    for env_over in (dict(CATPPO_ROWS_FWD_ROLLOUT="1", CATPPO_FUSED_FWD_MIN_ROWS="1"), dict(CATPPO_FUSED_FWD="0")):
+        out = str(tmp_path / f"rr{len(outs)}.npz")
+        code = TK._FUSED_FWD_AB.format(root=ROOT, cases=cases, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    f, l = outs
+    for k in f.files:
+        if k.endswith("_e3"):
+            np.testing.assert_array_equal(f[k], l[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(f[k], l[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(l[k]).max())), err_msg=k)
+    assert np.abs(f["cfg2_act"]).max() > 0 and np.isfinite(f["ragged_lp"]).all()
