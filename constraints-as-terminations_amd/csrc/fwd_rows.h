@@ -39,38 +39,56 @@ template <int R>
 constexpr size_t lds_bytes(int ld) { return sizeof(float) * ((size_t)R * ld + 8 * kRingWave); }
 
 // One 256-wide layer for the workgroup's R rows: acc[t] (rows 32 t .. 32 t + 31) = in[:, :K] . W[32 w .. 32 w + 31, :K]^T.
-// The wave's first weight slab must already be in `st` (requested by stage_first, so that its latency hides behind the
-// barriers / tile traffic in front of the layer).
+//
+// Weight pipeline of a wave (slabs of 32 k; ring slots A / B; ONE staging register set inside the loop):
+//     stage()   requests slabs 0 and 1 (two register sets) - issued by the caller in FRONT of whatever separates two
+//               layers (barriers, the in-place tile write), so that their latency hides there
+//     begin()   slot A <- slab 0, slot B <- slab 1, slab 2 requested
+//     loop()    slab s multiplies out of slot s & 1; its last block fetches the first fragments of slab s+1 (other
+//               slot, written at least one slab ago); at its end the staged slab s+2 overwrites slot s & 1 (every read
+//               of slab s has been issued: LDS operations of a wave execute in order) and slab s+3 is requested.
+// Why two slabs deep: the caller streams the PREVIOUS layer's activation tile out to memory between begin() and loop()
+// (write-through stores).  gfx9 counts loads and stores in ONE in-order counter (vmcnt), so a wait for a load issued
+// after those stores also waits for the stores.  Here the first such load is slab 3, requested at the end of slab 0 and
+// needed at the end of slab 1: the stores get two slabs (~3.7 us) to reach memory before anything waits behind them.
+// (The first version requested slab 1 behind the stores and needed it half a slab later: every layer stalled on its
+// predecessor's store tail, 57 us for what the matrix pipe does in 35.)
 template <int R>
 struct Layer {
   static constexpr int T = R / 32;
   const float* gp;                 // this lane's float4 of weight row (32 w + lane / 8), k quad lane % 8
   int64_t row8;                    // 8 weight rows further (floats)
-  float4 st[4];                    // staged slab: rows lane/8 + 8 j
+  float4 st[4], st1[4];            // staged slabs: rows lane/8 + 8 j  (st1: only between stage() and begin())
 
-  __device__ __forceinline__ void stage_first(const float* W, int K, int wave, int lane) {
+  __device__ __forceinline__ void gload(float4 (&d)[4], int s) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d[j] = *reinterpret_cast<const float4*>(gp + j * row8 + 32 * s);
+  }
+  __device__ __forceinline__ void lstore(float* slot, const float4 (&d)[4], int lane) const {
+    float* p = slot + (lane >> 3) * kWS + 4 * (lane & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(p + 8 * j * kWS) = d[j];
+  }
+  __device__ __forceinline__ void stage(const float* W, int K, int wave, int lane) {
     gp = W + (int64_t)(wave * 32 + (lane >> 3)) * K + 4 * (lane & 7);
     row8 = (int64_t)8 * K;
-    gload(0);
+    gload(st, 0);
+    gload(st1, 1);       // (a slab past the end of a short contraction reads the following weight rows: never multiplied)
   }
-  __device__ __forceinline__ void gload(int s) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st[j] = *reinterpret_cast<const float4*>(gp + j * row8 + 32 * s);
-  }
-  __device__ __forceinline__ void lstore(float* slot, int lane) {
-    float* d = slot + (lane >> 3) * kWS + 4 * (lane & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(d + 8 * j * kWS) = st[j];
+  __device__ __forceinline__ void begin(float* __restrict__ wring, int lane) {
+    lstore(wring, st, lane);
+    lstore(wring + kSlot, st1, lane);
+    gload(st, 2);
   }
 
   // one 32-k slab (NB = 4 blocks, or the 2-block tail of a contraction that is not a multiple of 32) out of ring slot
-  // `bs`; fragments of its block 0 are already in fa[0] / fb[0].  NEXT: another slab follows - its fragments of block 0
-  // are requested at the last block, the staged slab goes into the other slot `bn` and the slab after it is requested
-  // (a request past the last slab reads the next weight rows / the bias that follows the matrix: in bounds by the
-  // plan's check, never stored to a slot that is read).  No branch inside: the loop body is straight-line code.
-  template <int NB, bool NEXT>
+  // `bs`; fragments of its block 0 are already in fa[0] / fb[0].  NEXT: another slab follows (its block-0 fragments are
+  // requested at the last block, from `bn`).  REFILL: the staged slab s+2 goes into THIS slab's slot `mine` at the end
+  // and slab s+3 is requested (a request past the last slab reads the weight rows / the bias that follow: in bounds by
+  // the plan's check, never multiplied).  No branch inside: the loop body is straight-line code.
+  template <int NB, bool NEXT, bool REFILL>
   __device__ __forceinline__ void slab(const float* __restrict__ as, const int ld, const float* __restrict__ bs,
-                                       float* __restrict__ bn_slot, const float* __restrict__ bn, const int s,
+                                       float* __restrict__ mine, const float* __restrict__ bn, const int s,
                                        float4 (&fa)[2][T], float4 (&fb)[2], f32x16 (&acc)[T], const int lane) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
@@ -91,16 +109,12 @@ struct Layer {
       for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][t].x, fb[cur].x, acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][t].y, fb[cur].y, acc[t], 0, 0, 0);
-      if (NEXT && blk == 1) {
-        // the staged slab s+1 goes into the other slot (last read during slab s-1: those reads have been consumed)
-        // - between MFMAs, so that the issue of the four ds_write_b128 hides behind the matrix pipe
+      if (REFILL && blk == NB - 1) {
+        // every fragment read of this slab has been issued: its slot takes the staged slab s+2 - between MFMAs, so that
+        // the four ds_write_b128 and the four requests of slab s+3 issue behind the matrix pipe
         __builtin_amdgcn_sched_barrier(0);
-        lstore(bn_slot, lane);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (NEXT && blk == 2) {
-        __builtin_amdgcn_sched_barrier(0);
-        gload(s + 2);                                  // slab s+2 requested: a whole slab of MFMAs to arrive in
+        lstore(mine, st, lane);
+        gload(st, s + 3);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -111,8 +125,8 @@ struct Layer {
     }
   }
 
-  __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, float* __restrict__ wring,
-                                      const int K, f32x16 (&acc)[T], const int lane) {
+  __device__ __forceinline__ void loop(const float* __restrict__ tile, const int ld, float* __restrict__ wring,
+                                       const int K, f32x16 (&acc)[T], const int lane) {
     const int l31 = lane & 31, h = lane >> 5;
     const int nblk = K >> 3;                         // 8-k blocks of the contraction (K % 16 == 0)
     const int n_slabs = (nblk + 3) >> 2;             // 32-k slabs; the last one may hold 2 blocks
@@ -120,23 +134,34 @@ struct Layer {
     for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    lstore(wring, lane);                             // slab 0 (waits for stage_first's loads)
-    gload(1);
     const float* ap = tile + l31 * ld + 4 * h;       // A fragments: row l31 (+ 32 t), k = 32 s + 8 blk + 4 h ..
-    float* const bp = wring + l31 * kWS + 4 * h;     // B fragments inside a slot
-    float* const wr1 = wring + kSlot;
+    float* const w0 = wring;
+    float* const w1 = wring + kSlot;
+    const float* const bp = wring + l31 * kWS + 4 * h;     // B fragments inside a slot
     float4 fa[2][T], fb[2];
 #pragma unroll
     for (int t = 0; t < T; ++t) fa[0][t] = *reinterpret_cast<const float4*>(ap + 32 * t * ld);
     fb[0] = *reinterpret_cast<const float4*>(bp);
     int s = 0;
-    for (; s + 1 < n_slabs; ++s) {                   // every slab but the last: four blocks, a successor
-      const int o = (s & 1) * kSlot, on = kSlot - o;
-      slab<4, true>(ap + 32 * s, ld, bp + o, (s & 1) ? wring : wr1, bp + on, s, fa, fb, acc, lane);
+    if (n_slabs > 2) {
+      // the first refilling slab stands outside the loop: its wait for the staged slab 2 (requested in begin(), i.e.
+      // BEFORE the caller's activation stores) then gets an exact count, vmcnt(<stores>), instead of the vmcnt(0) a
+      // wait shared with the later iterations would need - which would stall on those stores
+      slab<4, true, true>(ap, ld, bp, w0, bp + kSlot, 0, fa, fb, acc, lane);
+      s = 1;
+    }
+    for (; s + 2 < n_slabs; ++s) {                   // slabs with two successors: refill their slot with slab s+2
+      const int o = (s & 1) * kSlot;
+      slab<4, true, true>(ap + 32 * s, ld, bp + o, (s & 1) ? w1 : w0, bp + (kSlot - o), s, fa, fb, acc, lane);
+    }
+    if (s + 1 < n_slabs) {                           // the last but one: a successor, nothing left to stage
+      const int o = (s & 1) * kSlot;
+      slab<4, true, false>(ap + 32 * s, ld, bp + o, nullptr, bp + (kSlot - o), s, fa, fb, acc, lane);
+      ++s;
     }
     const int o = (s & 1) * kSlot;
-    if (nblk - 4 * s == 4) slab<4, false>(ap + 32 * s, ld, bp + o, nullptr, nullptr, s, fa, fb, acc, lane);
-    else slab<2, false>(ap + 32 * s, ld, bp + o, nullptr, nullptr, s, fa, fb, acc, lane);
+    if (nblk - 4 * s == 4) slab<4, false, false>(ap + 32 * s, ld, bp + o, nullptr, nullptr, s, fa, fb, acc, lane);
+    else slab<2, false, false>(ap + 32 * s, ld, bp + o, nullptr, nullptr, s, fa, fb, acc, lane);
   }
 };
 

