@@ -431,13 +431,17 @@ class PPOTrainer:
         self.graph_fallback = None
         # gradient all-reduce in per-layer buckets on the library's side stream, under the backward launches of the
         # layers below (catppo_set_grad_overlap; cf. skrl/ppo.py:534-537, which reduces after the whole backward).
-        # Needs libcatppo's own communicator; default: on whenever there are real peers.
+        # Needs libcatppo's own communicator.  OPT-IN (cfg ``grad_overlap`` / CATPPO_GRAD_OVERLAP=1): measured on a world of
+        # one with every exchange point forced on (profiles/r4_grad_overlap_world1.txt) the two fork / join pairs and the
+        # per-bucket fold launches cost +29 us per optimiser step (9.50 -> 10.38 ms of update phase at cfg2) - more than a
+        # 1.5 MB ring all-reduce over xGMI is expected to take serialised, so it only pays on a fabric
+        # where that all-reduce is slower than ~30 us.
         go = getattr(c, "grad_overlap", None)
         env_go = os.environ.get("CATPPO_GRAD_OVERLAP")
         if env_go is not None:
             go = env_go == "1"
         if go is None:
-            go = self.world > 1
+            go = False
         self.grad_overlap = False
         if parallel.active() and parallel.native_comm_active():
             self.grad_overlap = self.nat.set_grad_overlap(bool(go))
