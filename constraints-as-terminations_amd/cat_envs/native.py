@@ -86,7 +86,8 @@ class RolloutStep(C.Structure):
         ("obs_raw", C.c_void_p), ("obs_ld", C.c_int64),
         ("obs_mean", C.c_void_p), ("obs_var", C.c_void_p), ("obs_count", C.c_void_p), ("obs_eps", C.c_float),
         ("obs_rows_total", C.c_double), ("obs_out", C.c_void_p), ("obs_out_ld", C.c_int64),
-        ("xchg", C.c_void_p), ("xchg_gathered", C.c_void_p), ("xchg_records", C.c_int32)]
+        ("xchg", C.c_void_p), ("xchg_gathered", C.c_void_p), ("xchg_records", C.c_int32),
+        ("sim_src", C.c_void_p), ("sim_state", C.c_void_p), ("sim_row_bytes", C.c_int64)]
 
 
 F32, F16, F64 = 0, 1, 2                 # CATPPO_F32 / _F16 / _F64

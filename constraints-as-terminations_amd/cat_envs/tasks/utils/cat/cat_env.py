@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import types
 from collections.abc import Sequence
 
@@ -38,6 +39,10 @@ DEFAULT_JOINT_POS = [0.05, 0.4, -0.8, -0.05, 0.4, -0.8, 0.05, 0.4, -0.8, -0.05, 
 class _Space:
     def __init__(self, shape):
         self.shape = tuple(shape)
+
+
+#: the fused env step advances the simulator state inside catppo_rollout_pre (A/B switch, read once)
+_FUSED_SIM_COPY = os.environ.get("CATPPO_FUSED_SIM_COPY", "1") != "0"
 
 
 class SyntheticSolo12Sim:
@@ -130,9 +135,14 @@ class SyntheticSolo12Sim:
             first_contact_f32=fc, compute_first_contact=lambda dt: fc > 0.5)
         self.scene = {"robot": robot, "contact_forces": sensor}
 
-    def step(self):
+    def advance(self) -> torch.Tensor:
+        """move to the next step of the stream WITHOUT touching the state buffer: returns the slab that holds the new
+        state (the fused env step hands it to catppo_rollout_pre, which copies it into ``cur`` inside its own launch)"""
         self.cursor = (self.cursor + 1) % self.S
-        self.cur.copy_(self._slabs[self.cursor])               # "scene.update": one contiguous slab
+        return self._slabs[self.cursor]
+
+    def step(self):
+        self.cur.copy_(self.advance())                         # "scene.update": one contiguous slab
 
 
 class _ActionManager:
@@ -298,7 +308,14 @@ class CaTEnv:
         nat = self._nat
         cm = self.constraint_manager
         self._sim_step_counter += self.cfg.decimation
-        self.sim.step()
+        # "scene.update": the new simulator state.  Fused: catppo_rollout_pre copies the stream's next slab into the state
+        # buffer inside its own launch and reads its inputs straight from the slab (catppo_rollout_step.sim_src) - one
+        # 5 us copy kernel and a launch boundary less per env step; CATPPO_FUSED_SIM_COPY=0 keeps the separate copy.
+        slab = None
+        if _FUSED_SIM_COPY:
+            slab = self.sim.advance()
+        else:
+            self.sim.step()
         self.common_step_counter += 1
         st = self._rstep
         if st is None:
@@ -322,10 +339,12 @@ class CaTEnv:
             st.xchg = self._xchg.data_ptr()
             self._xchg_views = nat.rollout_xchg_views(self._xchg, cm.cat._p_cstr.shape[1], self.obs_dim)
             self._xchg_all = None
+            st.sim_state, st.sim_row_bytes = self.sim.cur.data_ptr(), self.sim.F * 4
             self._rstep_ref = C.byref(st)
         if action.dtype != torch.float32 or not action.is_contiguous():
             action = action.float().contiguous()
         st.action_in = action.data_ptr()
+        st.sim_src = slab.data_ptr() if slab is not None else None
         cm.fill_rollout_step(st)
         sink.fill(st)
         lib, h, stream = nat.lib, nat.h, nat._stream()

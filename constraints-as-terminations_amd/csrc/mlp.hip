@@ -2430,6 +2430,11 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     }
     static const bool no_pair = getenv("CATPPO_NO_PAIR") != nullptr;
     const bool pair = l > 0 && !fork && !no_pair;
+    // (round 4, measured and removed: a 256 x 64 tile for the narrow first layer - one workgroup per CU owning all 256
+    // output rows of a network for its slice of the batch, dZ_0 and the observations read once - was 3.5 us per step
+    // SLOWER than the 64x64 tiling, 9.48 vs 9.39 ms of update phase, profiles/r4_ab_dw0_tile.txt: twice the partial
+    // bytes for the fold and 64 single-dword write-through stores per lane in the epilogue of a workgroup that only
+    // multiplies 8 slabs)
     if (!pair) {
       launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
       CATPPO_CHECK_LAUNCH(ctx);

@@ -70,6 +70,10 @@ struct PreArgs {
   float* x_colmax;          // exchange buffer
   double* x_sums;
   unsigned int* ticket;     // [0] = launch-wide ticket, [1 + g] = ticket of workgroup group g
+  // simulator state advance (catppo_rollout_step::sim_src): rows of row_q4 float4 copied src -> dst by the tile's workgroup
+  const float4* sim_src;
+  float4* sim_dst;
+  int sim_row_q4;
 };
 constexpr int kFoldGroup = 32;    // workgroups per first-level fold
 constexpr int kMaxPreBlocks = 1024;
@@ -166,6 +170,14 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
     const int64_t r0 = tl * kRows;
     const int rows = (int)((a.N - r0) < kRows ? (a.N - r0) : kRows);
+
+    // ---- simulator state advance: this tile's rows of the new state block go to the persistent state buffer.  Nothing
+    //      in this launch reads the destination (every state input has been re-based onto the source by the host side),
+    //      so the copy is independent traffic beside the dependent load chains of the terms below.
+    if (a.sim_src != nullptr) {
+      const int64_t base = r0 * a.sim_row_q4;
+      for (int e = threadIdx.x; e < rows * a.sim_row_q4; e += kThreads) a.sim_dst[base + e] = a.sim_src[base + e];
+    }
 
     // ---- constraint terms (the action-rate term reads action_in / the not yet shifted action buffer)
     for (int t = wave; t < tab.n; t += kThreads / 64) {
@@ -575,6 +587,22 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
       CATPPO_CHECK_ARG(ctx, d.x != a->action && d.x != a->prev_action && d.y != a->action && d.y != a->prev_action);
     }
   }
+  // simulator state advance inside this launch: re-base every input that lives in the state block onto the new block
+  const char* st_lo = static_cast<const char*>(a->sim_state);
+  const int64_t st_bytes = a->N * a->sim_row_bytes;
+  if (a->sim_src != nullptr) {
+    CATPPO_CHECK_ARG(ctx, a->sim_state != nullptr && a->sim_row_bytes >= 16 && a->sim_row_bytes % 16 == 0);
+    CATPPO_CHECK_ARG(ctx, (reinterpret_cast<uintptr_t>(a->sim_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->sim_state) & 15) == 0);
+  }
+  auto rebase = [&](const float* q) -> const float* {
+    const char* c = reinterpret_cast<const char*>(q);
+    if (a->sim_src == nullptr || c == nullptr || c < st_lo || c >= st_lo + st_bytes) return q;
+    return reinterpret_cast<const float*>(static_cast<const char*>(a->sim_src) + (c - st_lo));
+  };
+  for (int t = 0; t < tab.n; ++t) {
+    tab.d[t].x = rebase(static_cast<const float*>(tab.d[t].x));
+    tab.d[t].y = rebase(static_cast<const float*>(tab.d[t].y));
+  }
   const size_t lds = sizeof(float) * ((size_t)kRows * a->K + a->K);
   CATPPO_CHECK_ARG(ctx, lds <= 150 * 1024);
   // few, fatter workgroups: the partial rows (= grid size) are folded by ONE workgroup at the end of the launch, so
@@ -598,13 +626,15 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
   p.N = a->N, p.A = a->A, p.D = a->D, p.K = a->K;
   p.action_in = a->action_in, p.action = a->action, p.prev_action = a->prev_action;
   p.ep_len = a->episode_length, p.max_len = a->max_episode_length;
-  p.hard_reset = a->hard_reset, p.hr_stride = a->hard_reset_stride;
-  p.reward_src = a->reward_src, p.rw_stride = a->reward_stride;
+  p.hard_reset = rebase(a->hard_reset), p.hr_stride = a->hard_reset_stride;
+  p.reward_src = rebase(a->reward_src), p.rw_stride = a->reward_stride;
   p.time_outs = a->time_outs, p.terminated = a->terminated, p.reset = a->reset, p.reward = a->reward;
-  p.forces = a->forces, p.fstride = a->forces_env_stride, p.H = a->H, p.B = a->B;
-  p.command = a->command, p.cld = a->command_ld;
+  p.forces = rebase(a->forces), p.fstride = a->forces_env_stride, p.H = a->H, p.B = a->B;
+  p.command = rebase(a->command), p.cld = a->command_ld;
   p.cstr = a->cstr;
-  p.obs_raw = a->obs_raw, p.obs_ld = a->obs_ld;
+  p.obs_raw = rebase(a->obs_raw), p.obs_ld = a->obs_ld;
+  p.sim_src = static_cast<const float4*>(a->sim_src), p.sim_dst = static_cast<float4*>(a->sim_state);
+  p.sim_row_q4 = (int)(a->sim_row_bytes / 16);
   p.colmax_partial = cpart, p.osum_partial = opart;
   p.colmax_group = cgrp, p.osum_group = ogrp;
   p.x_colmax = static_cast<float*>(a->xchg);

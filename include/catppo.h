@@ -512,6 +512,15 @@ typedef struct catppo_rollout_step {
    * (identical on every rank).  xchg_records = number of records (0 / 1: read `xchg`, e.g. after MAX / SUM all-reduces). */
   const void* xchg_gathered;
   int32_t xchg_records;
+  /* ABI 0.4: the simulator's state advance inside catppo_rollout_pre.  A simulator whose new state already exists as
+   * one contiguous [N, sim_row_bytes] block somewhere else (here: the synthetic stream's next slab; the reference's
+   * `scene.update`, cat/cat_env.py:60-90, is that copy) hands it over as `sim_src`: every input of THIS call that points
+   * into the state block [sim_state, sim_state + N * sim_row_bytes) - term tensors, forces, command, hard_reset,
+   * reward_src, obs_raw - is read from `sim_src` at the same offset, and the launch copies the rows to `sim_state`
+   * (each workgroup its own envs), so that after it every view of the state block is current (catppo_rollout_post and
+   * everybody else read it as before).  One launch and a 5 us copy kernel less per env step.  sim_src == NULL: the
+   * caller has updated the state block itself.  sim_row_bytes % 16 == 0. */
+  const void* sim_src; void* sim_state; int64_t sim_row_bytes;
 } catppo_rollout_step;
 uint64_t catppo_rollout_xchg_bytes(int K, int D);
 uint64_t catppo_rollout_step_sizeof(void);   /* sizeof(catppo_rollout_step): lets a binding check its struct layout */
