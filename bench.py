@@ -183,7 +183,8 @@ def pmc_traffic(workload, tag):
     return d.get("hbm_bytes_per_launch"), os.path.basename(path), None
 
 
-GROUP_KERNELS = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel")
+GROUP_KERNELS = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel",
+                 "rows_fwd_kernel")
 
 
 def profiled_group_us(workload, tag):
@@ -208,7 +209,7 @@ def profiled_group_us(workload, tag):
     for r in rows:
         if not any(k in r["kernel"] for k in GROUP_KERNELS + ("fold_",)):
             continue
-        if "<64, 64, true, true, 0, 64" in r["kernel"] or "policy_fwd" in r["kernel"]:
+        if "<64, 64, true, true, 0, 64" in r["kernel"] or "policy_fwd" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"]:
             continue                                   # rollout-only launches (<= 4096 rows)
         if "<64, 64, true, true, 0" in r["kernel"]:    # first-layer forward: the rollout uses the same kernel on fewer rows
             if blocks(r) < max(blocks(q) for q in rows if q["kernel"] == r["kernel"]):
@@ -491,9 +492,10 @@ def main():
                             "timed region (serialised wire time)"},
             "phases_device_ms": phases,
             "iteration_tflops": it_flops / (1e9 * dt / a.steps) / 1e3,
-            "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (grouped fp32-MFMA forward GEMM launches, the last one "
-                         "with heads + loss + head backward in its epilogue from 4096 rows up, else a head+loss launch; "
-                         "paired split-K dW + dX GEMM launches, partial fold) per " + str(M) + "-sample minibatch",
+            "roofline": {"bound": "mfma", "kernel": "catppo_ppo_minibatch_grad_packed (row-resident fp32-MFMA forward of the hidden layers "
+                         "below the last - or grouped forward GEMM launches - then the last layer with heads + loss + head backward "
+                         "in its epilogue from 4096 rows up, else a head+loss launch; paired split-K dW + dX GEMM launches, "
+                         "partial fold) per " + str(M) + "-sample minibatch",
                          "achieved": ach * mfma_flops_factor, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach * mfma_flops_factor / peak, "algorithmic_tflops": ach,
                          "executed_over_algorithmic_flops": mfma_flops_factor,

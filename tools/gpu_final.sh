@@ -1,6 +1,7 @@
 #!/bin/bash
 # final validation + profile refresh: everything that gets committed under profiles/ is produced here
 set -u
+TAG=${TAG:-r4}
 REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
@@ -12,33 +13,49 @@ tail -6 "$OUT/final_tests.log" | cut -c1-220
 echo "== smoke ($(( $(date +%s) - T0 )) s)"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 echo "== profile passes first (the bench line then finds a PMC summary stamped with this tree) ($(( $(date +%s) - T0 )) s)"
-bash tools/profile_bench.sh cfg2 r3 > "$OUT/final_profile.log" 2>&1
-python tools/pmc_sq_summary.py "$OUT/r3_pmc_sq1_cfg2.csv" "$OUT/r3_pmc_sq2_cfg2.csv" > "$OUT/r3_pmc_sq_summary_cfg2.json" 2>/dev/null
-mkdir -p profiles && cp "$OUT/r3_pmc_traffic_cfg2.json" "$OUT/r3_bench_cfg2_kernel_stats.csv" profiles/ 2>/dev/null
+bash tools/profile_bench.sh cfg2 $TAG > "$OUT/final_profile.log" 2>&1
+python tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq1_cfg2.csv" "$OUT/${TAG}_pmc_sq2_cfg2.csv" > "$OUT/${TAG}_pmc_sq_summary_cfg2.json" 2>/dev/null
+mkdir -p profiles && cp "$OUT/${TAG}_pmc_traffic_cfg2.json" "$OUT/${TAG}_bench_cfg2_kernel_stats.csv" profiles/ 2>/dev/null
 echo "== bench lines ($(( $(date +%s) - T0 )) s)"
-timeout 400 python bench.py 2> "$OUT/r3_bench_cfg2.err" | tail -1 > "$OUT/r3_bench_cfg2.json"
+timeout 400 python bench.py 2> "$OUT/${TAG}_bench_cfg2.err" | tail -1 > "$OUT/${TAG}_bench_cfg2.json"
 B="timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
-$B --workload reference 2>/dev/null | tail -1 > "$OUT/r3_bench_reference.json"
-$B --workload cfg2 --mlp-precision bf16x3 2>/dev/null | tail -1 > "$OUT/r3_bench_cfg2_bf16x3.json"
-: > "$OUT/r3_bench_other_configs.jsonl"
-for WL in cfg1 cfg3 cfg3_shard cfg4 cfg5 cfg5_envs; do $B --workload $WL 2>/dev/null | tail -1 >> "$OUT/r3_bench_other_configs.jsonl"; done
-CATPPO_FORCE_DIST=1 $B --workload cfg2 2>/dev/null | tail -1 > "$OUT/r3_bench_cfg2_forced_dist_world1.json"
-: > "$OUT/r3_bench_cfg3_shares.jsonl"
-for W in 1 2 4 8; do $B --workload cfg3 --shard-of $W 2>/dev/null | tail -1 >> "$OUT/r3_bench_cfg3_shares.jsonl"; done
-python - "$OUT" <<'PY'
+$B --workload reference 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_reference.json"
+$B --workload cfg2 --mlp-precision bf16x3 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_cfg2_bf16x3.json"
+: > "$OUT/${TAG}_bench_other_configs.jsonl"
+for WL in cfg1 cfg3 cfg3_shard cfg4 cfg5 cfg5_envs; do $B --workload $WL 2>/dev/null | tail -1 >> "$OUT/${TAG}_bench_other_configs.jsonl"; done
+CATPPO_FORCE_DIST=1 $B --workload cfg2 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_cfg2_forced_dist_world1.json"
+: > "$OUT/${TAG}_bench_cfg3_shares.jsonl"
+for W in 1 2 4 8; do $B --workload cfg3 --shard-of $W 2>/dev/null | tail -1 >> "$OUT/${TAG}_bench_cfg3_shares.jsonl"; done
+echo "== launcher proof: bench.py starts two ranks itself (one GPU: gloo host staging) ($(( $(date +%s) - T0 )) s)"
+timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2> "$OUT/${TAG}_bench_cfg2_gpus2_selflaunch.err" | tail -1 > "$OUT/${TAG}_bench_cfg2_gpus2_selflaunch.json"
+echo "== three more default lines back to back (run-to-run spread) ($(( $(date +%s) - T0 )) s)"
+: > "$OUT/${TAG}_bench_cfg2_repeats.jsonl"
+for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/${TAG}_bench_cfg2_repeats.jsonl"; done
+if [ -f tools/bin/libcatppo_fftl.so ]; then
+  echo "== rows_fwd timeline ($(( $(date +%s) - T0 )) s)"
+  (CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 48 2; CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 240 2) 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_rows_fwd_timeline.txt"
+fi
+python - "$OUT" "$TAG" <<'PY'
 import json,sys,os
-out=sys.argv[1]
+out=sys.argv[1]; TAG=sys.argv[2]
 def show(tag,line):
     try:
         d=json.loads(line)
         print(tag, round(d["value"]/1e6,3),"M/s ms",round(d["ms_per_step"],2),"grp_us",round(d["roofline"]["avg_launch_us"],1),"frac",round(d["roofline"]["frac"],3),"traffic",d["roofline"]["traffic"],{k:round(v,2) for k,v in d["phases_device_ms"].items() if k!="iterations"})
     except Exception as e: print(tag,"FAILED",e)
-for f in ("r3_bench_cfg2.json","r3_bench_reference.json","r3_bench_cfg2_bf16x3.json","r3_bench_cfg2_forced_dist_world1.json"):
+for f in tuple(TAG + x for x in ("_bench_cfg2.json","_bench_reference.json","_bench_cfg2_bf16x3.json","_bench_cfg2_forced_dist_world1.json")):
     show(f, open(os.path.join(out,f)).read().strip().splitlines()[-1])
-for l in open(os.path.join(out,"r3_bench_other_configs.jsonl")):
+for f in (TAG + "_bench_cfg2_gpus2_selflaunch.json",):
+    try:
+        d=json.loads(open(os.path.join(out,f)).read().strip().splitlines()[-1])
+        print(f, "n_gpus", d["n_gpus"], "physical", d["physical_gpus"], round(d["value"]/1e6,3), "M/s comm_ms", d["comm_ms_per_iteration"], d["config"]["collectives"][:40])
+    except Exception as e: print(f, "FAILED", e)
+for l in open(os.path.join(out,TAG + "_bench_cfg2_repeats.jsonl")):
+    if l.strip(): show("repeat", l)
+for l in open(os.path.join(out,TAG + "_bench_other_configs.jsonl")):
     if l.strip(): show(json.loads(l)["config"]["workload"][:12], l)
-for l in open(os.path.join(out,"r3_bench_cfg3_shares.jsonl")):
+for l in open(os.path.join(out,TAG + "_bench_cfg3_shares.jsonl")):
     if l.strip(): show("cfg3 share of W=%s" % json.loads(l)["config"]["simulated_shard_of_world"], l)
 PY
-cat "$OUT/r3_bench_cfg2.err" | grep bench
+cat "$OUT/${TAG}_bench_cfg2.err" | grep bench
 echo "== done ($(( $(date +%s) - T0 )) s)"

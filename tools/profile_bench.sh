@@ -6,7 +6,7 @@
 # Counter passes are separate runs with nothing but --pmc (gpurun refuses --pmc mixed with trace domains).
 set -u
 WL=${1:-cfg2}
-TAG=${2:-r3}
+TAG=${2:-r4}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
