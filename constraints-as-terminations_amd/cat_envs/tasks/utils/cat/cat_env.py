@@ -7,9 +7,10 @@ hard resets, manager resets, return tuple); the physics loop (:61-88) is Isaac S
 which cannot run on AMD GPUs and is out of scope.  This class therefore drives the same
 managers from a *synthetic simulator*: seeded, device-resident, pre-generated streams of Solo12
 sim state (joint state, gravity, commands, contact forces, air times), rewards, hard resets
-and observations.  One ``copy_`` per step moves the current slab of the stream into
-persistent state buffers (what a simulator's ``scene.update`` does); every manager reads
-views of those buffers, exactly like IsaacLab's ``scene[...]`` data objects.
+and observations.  Every step the current slab of the stream is moved into persistent state
+buffers (what a simulator's ``scene.update`` does) - by one ``copy_`` in ``step``, inside the
+first launch of the fused ``step_into`` (``catppo_rollout_step.sim_src``) - and every manager
+reads views of those buffers, exactly like IsaacLab's ``scene[...]`` data objects.
 
 No host synchronisation happens inside ``step``: resets are handled with masks
 (``exact_reset_sync=True`` restores the reference's ``nonzero()``-based control flow).

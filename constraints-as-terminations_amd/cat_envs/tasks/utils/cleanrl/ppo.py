@@ -9,16 +9,19 @@ value losses, global-norm clip, Adam, linear lr anneal :294-354); every tensor o
 runs in libcatppo.so (hand-written HIP, see include/catppo.h):
 
     iteration      catppo_iter_begin                          (iteration counter, lr schedule: device state)
-    rollout step   catppo_policy_act_rng                      (3 GEMM launches + head: actions/logprobs/values[step];
-                                                               Philox action noise inside the head kernel)
-                   env.step_into -> catppo_rollout_pre/_post  (terms, CaT, resets, buffer rows, obs normaliser:
-                                                               2 launches; a foreign env takes the unfused calls)
+    rollout step   catppo_policy_act_rng                      (ONE launch at 2049-4096 rows - all hidden layers + heads
+                                                               per 32-row workgroup - else 3 GEMM launches + head:
+                                                               actions/logprobs/values[step]; Philox action noise inside)
+                   env.step_into -> catppo_rollout_pre/_post  (simulator state advance, terms, CaT, resets, buffer rows,
+                                                               obs normaliser: 2 launches; a foreign env takes the
+                                                               unfused calls)
     after rollout  catppo_value, catppo_gae, 2x (catppo_rms_update + catppo_rms_normalize)
     epoch          catppo_ppo_gather_ex                       (keyed on-device permutation, no index array)
     minibatch      catppo_ppo_minibatch_grad_packed  [catppo_allreduce: RCCL SUM of the flat gradient]
                    catppo_clip_adam_dev                       (lr / step count from the device state)
     [KL-adaptive]  catppo_kl_mean [catppo_allreduce] catppo_kl_adaptive_lr   after every epoch, no host sync
-The update phase can be replayed from a hipGraph (``graph_update``).
+The update phase is replayed from a hipGraph (``graph_update``; collectives of an env-sharded run included, with a
+reported eager fallback when the capture fails).
 
 There is no host synchronisation inside an iteration (the reference syncs once per
 constraint term per env step and once per minibatch); diagnostics accumulate on the device
@@ -446,6 +449,7 @@ class PPOTrainer:
         if parallel.active() and parallel.native_comm_active():
             self.grad_overlap = self.nat.set_grad_overlap(bool(go))
         self._graph_id = None
+        self._eager_updates_left = 1 if parallel.active() else 0
         self.graph_nodes = 0
         self.stream = torch.cuda.Stream(device=dev) if self.graph_update else None
         # first observation (ppo.py:186-189)
@@ -627,7 +631,11 @@ class PPOTrainer:
             perms = [perm_fn(e) for e in range(E)]
         elif self.rng == "torch":
             perms = [torch.randperm(B, device=self.device) for e in range(E)]
-        if self.graph_update and perms is None and not self.record_noise:
+        if self.graph_update and perms is None and not self.record_noise and self._eager_updates_left > 0:
+            # env-sharded runs: the FIRST update phase runs eagerly, so that RCCL's first collectives of every size
+            # (channel set-up, lazily loaded kernels, possibly allocations) happen outside a stream capture
+            self._eager_updates_left -= 1
+        elif self.graph_update and perms is None and not self.record_noise:
             if self._graph_id is not None:
                 try:
                     self.nat.graph_launch(self._graph_id)

@@ -11,6 +11,9 @@
 // deterministic two-stage reduction (no float atomics => run-to-run reproducible); a layer's
 // weight-gradient and data-gradient GEMMs share one launch (gemm_pair_kernel), the minibatch is
 // gathered once per epoch (catppo_ppo_gather) and every partial is folded by one launch.
+// Round 4: the hidden layers below the last one of a 256-wide network run as ONE row-resident launch
+// (rows_fwd_kernel, fwd_rows.h) in the update phase, the same kernel with heads is the rollout forward, and the
+// first layer's weight-gradient launch carries the fold of the layers above it (dw_fold_kernel).
 #include "common.h"
 #include "gemm_f32.h"
 #include "rng.h"
@@ -1727,9 +1730,9 @@ __device__ __forceinline__ float4 seg_sum4(const float* __restrict__ src, int64_
   return a;
 }
 
-__global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
-  __shared__ __attribute__((aligned(16))) float sm[1024];
-  const Seg sg = t.s[blockIdx.y];
+// one workgroup's share of one segment: workgroup bx of nbx walks the segment's elements (sm: 1024 floats of LDS)
+__device__ __forceinline__ void seg_reduce_body(const Seg sg, const int bx, const int nbx, float* __restrict__ sm,
+                                                const float ent_coef, const float vf_coef) {
   // few wide partials (split-K): 4 part groups x 64 lanes; many narrow ones (head): 16 x 16
   const int G = sg.n_parts >= 128 ? 16 : 4;
   const int EL = 256 / G;
@@ -1740,7 +1743,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float
     const int last = sg.n_parts - 1;
     const bool few = (sg.n_parts + G - 1) / G <= 4;         // parts per thread
     float4* sm4 = reinterpret_cast<float4*>(sm);
-    for (int64_t e0 = (int64_t)blockIdx.x * EL * 4; e0 < sg.count; e0 += (int64_t)gridDim.x * EL * 4) {
+    for (int64_t e0 = (int64_t)bx * EL * 4; e0 < sg.count; e0 += (int64_t)nbx * EL * 4) {
       const int64_t e = e0 + el * 4;
       float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (e < sg.count && g <= last) a = few ? seg_sum4<4>(sg.src + e, sg.stride, g, G, last)
@@ -1758,7 +1761,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float
     }
     return;
   }
-  for (int64_t e0 = (int64_t)blockIdx.x * EL; e0 < sg.count; e0 += (int64_t)gridDim.x * EL) {
+  for (int64_t e0 = (int64_t)bx * EL; e0 < sg.count; e0 += (int64_t)nbx * EL) {
     const int64_t e = e0 + el;
     float a = 0.0f;
     if (e < sg.count) {
@@ -1785,6 +1788,31 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float
       }
     }
     __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
+  __shared__ __attribute__((aligned(16))) float sm[1024];
+  seg_reduce_body(t.s[blockIdx.y], blockIdx.x, gridDim.x, sm, ent_coef, vf_coef);
+}
+
+// The first layer's weight-gradient GEMM and the fold of every OTHER layer's partials in one launch (round 4).  dW_0 is
+// the last GEMM of an optimiser step (it needs dZ_0, the output of the last paired launch) and a light one (0.8 GFLOP,
+// 37 MB); the partials of the layers above it have been complete since their own launches.  Their fold (43 MB of
+// streaming reads, no matrix work) used to wait behind it in a launch of its own; here its workgroups fill the CUs
+// beside the GEMM's, the way the paired launches mix long and short workgroups.  Workgroups [0, n_gemm) run the GEMM
+// (launch order first: they are resident from the start), the rest fold: kFoldX workgroups per segment.
+constexpr int kFoldX = 256;
+__global__ __launch_bounds__(256) void dw_fold_kernel(const gemm::Params p, const SegTable t, const int gemm_tiles,
+                                                      const int n_gemm, float ent_coef, float vf_coef) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < n_gemm) {
+    const gemm::TileId id = gemm::xcd_tile_of(b, gemm_tiles, n_gemm / gemm_tiles, p.xcd_legacy);
+    gemm::gemm_body<64, 64, false, false, gemm::EPI_PARTIAL>(p, id.tile, id.bz, smem);
+  } else {
+    const int f = b - n_gemm;
+    seg_reduce_body(t.s[f / kFoldX], f % kFoldX, kFoldX, smem, ent_coef, vf_coef);
   }
 }
 
@@ -2435,7 +2463,20 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     // SLOWER than the 64x64 tiling, 9.48 vs 9.39 ms of update phase, profiles/r4_ab_dw0_tile.txt: twice the partial
     // bytes for the fold and 64 single-dword write-through stores per lane in the epilogue of a workgroup that only
     // multiplies 8 slabs)
-    if (!pair) {
+    // the first layer's weight gradient shares its launch with the fold of the layers above it (dw_fold_kernel) when it
+    // is the plain 64x64-tile fp32 launch on the caller's stream; CATPPO_DW0_FOLD=0 keeps GEMM and fold apart (A/B)
+    static const int dw0_fold = env_int("CATPPO_DW0_FOLD", 1);
+    const bool dw_with_fold = !pair && l == 0 && dw0_fold && !fork && !overlap && bf16 == 0 && segs.n > 0 &&
+                              !(pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256);      // launch_gemm_auto's 128x128 rule
+    if (dw_with_fold) {
+      const int t64 = tiles_of<64, 64>(pw), n_gemm = t64 * pw.nets * pw.splits;
+      constexpr size_t lds = gemm::smem_bytes<64, 64, false, false>();
+      static_assert(lds >= 4096, "the fold workgroups use 1024 floats of the same allocation");
+      hipLaunchKernelGGL(dw_fold_kernel, dim3((unsigned)(n_gemm + kFoldX * segs.n)), dim3(256), lds, s, pw, segs, t64, n_gemm,
+                         hp->ent_coef, hp->vf_coef);
+      CATPPO_CHECK_LAUNCH(ctx);
+      segs.n = 0;        // folded; what is added below (this layer's own partials) goes to the final fold launch
+    } else if (!pair) {
       launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
       CATPPO_CHECK_LAUNCH(ctx);
     }

@@ -206,3 +206,25 @@ def test_row_resident_rollout_forward_equals_the_layerwise_path(tmp_path):
         else:
             np.testing.assert_allclose(f[k], l[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(l[k]).max())), err_msg=k)
     assert np.abs(f["cfg2_act"]).max() > 0 and np.isfinite(f["ragged_lp"]).all()
+
+
+@pytest.mark.parametrize("D,A,hidden,Bsz,M", [
+    (48, 12, (256, 256, 256), 16384, 16384),      # cfg2
+    (45, 12, (512, 256, 128), 4133, 2048),        # reference shapes, small ragged minibatch (head_loss path)
+])
+def test_first_layer_weight_gradient_launch_carrying_the_fold_is_bit_identical(tmp_path, D, A, hidden, Bsz, M):
+    """dw_fold_kernel (the first layer's weight-gradient GEMM + the fold of every other layer's partials in one launch)
+    against the separate GEMM and the single fold launch: same partials, same fold order per element - the flat gradient
+    and the diagnostics must be BIT-identical.  Two processes (CATPPO_DW0_FOLD is read once)."""
+    import test_gpu_kernels as TK
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"dwfold{flag}.npz")
+        code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=0, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CATPPO_DW0_FOLD=flag), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.abs(outs[1]["grad"]).max() > 0
+    np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
+    np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
