@@ -184,7 +184,7 @@ def pmc_traffic(workload, tag):
 
 
 GROUP_KERNELS = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel",
-                 "rows_fwd_kernel")
+                 "rows_fwd_kernel", "dw_fold_kernel")
 
 
 def profiled_group_us(workload, tag):
@@ -199,7 +199,7 @@ def profiled_group_us(workload, tag):
     except OSError:
         return None, None
     try:
-        n_mb = next(int(r["calls"]) for r in rows if "seg_reduce" in r["kernel"] or "fold_" in r["kernel"])
+        n_mb = next(int(r["calls"]) for r in rows if "seg_reduce" in r["kernel"])      # one (final) fold launch per minibatch
     except StopIteration:
         return None, os.path.basename(path)
     def blocks(r):
@@ -207,7 +207,7 @@ def profiled_group_us(workload, tag):
         return x * y * z
     us = 0.0
     for r in rows:
-        if not any(k in r["kernel"] for k in GROUP_KERNELS + ("fold_",)):
+        if not any(k in r["kernel"] for k in GROUP_KERNELS):
             continue
         if "<64, 64, true, true, 0, 64" in r["kernel"] or "policy_fwd" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"]:
             continue                                   # rollout-only launches (<= 4096 rows)
