@@ -161,6 +161,7 @@ def test_failed_graph_replay_falls_back_to_eager_launches_and_says_so():
 @pytest.mark.parametrize("D,A,hidden,Bsz,M", [
     (48, 12, (256, 256, 256), 16384, 16384),      # cfg2's minibatch: 256 row tiles, one workgroup walks both networks
     (48, 12, (256, 256, 256), 8192, 4133),        # ragged, 65 tiles: one workgroup per (tile, network), last tile 37 rows
+    (48, 12, (256, 256, 256), 16421, 16421),      # ragged AND >= 256 tiles: both networks per workgroup, 37-row last tile
     (235, 12, (256, 256, 256), 8192, 8192),       # cfg4: 240-wide padded observations (7.5 slabs of 32)
     (48, 12, (256, 256), 4160, 4160),             # two hidden layers: only the first one is computed by the new launch
     (45, 5, (256, 256, 256, 128), 4096, 4096),    # three fused layers below a 128-wide last layer
