@@ -229,3 +229,22 @@ def test_first_layer_weight_gradient_launch_carrying_the_fold_is_bit_identical(t
     assert np.abs(outs[1]["grad"]).max() > 0
     np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
     np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
+
+
+@pytest.mark.parametrize("D", [5, 17, 50, 70, 100, 250])
+def test_row_resident_forward_every_slab_count_of_the_first_layer(tmp_path, D):
+    """the first layer's contraction length decides which pieces of the slab loop run (padded widths 16 / 32 / 64 / 80 /
+    112 / 256 = 1, 1, 2, 3, 4, 8 slabs of 32 k, the last one 2 or 4 blocks long; peeled first refill, refill loop, last but
+    one, last): whole minibatch gradient bit-identical to the layer-wise launches at every one of them (4101 ragged rows)"""
+    import test_gpu_kernels as TK
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"rows{flag}.npz")
+        code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=12, hidden=(256, 256, 256), Bsz=4101, M=4101, prec=0, out=out)
+        env = dict(os.environ, CATPPO_ROWS_FWD=flag, CATPPO_ROWS_FWD_MIN_ROWS="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.abs(outs[1]["grad"]).max() > 0
+    np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
+    np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
