@@ -1,3 +1,8 @@
+"""Phase timeline of the rollout forward (rows_fwd_kernel<32> with heads: one workgroup per (32-row tile, network)): wall-clock
+stamps of thread 0 of every workgroup + shader-clock stamps around the last layer's contraction.  Needs -DFUSED_TL:
+    python constraints-as-terminations_amd/build.py --variant fftl -DFUSED_TL
+    CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so python tools/rows32_rollout_timeline.py
+stamp indices: 0 entry, 1 observation tile in LDS, 2 + 2 l contraction of layer l done (wave 0), 3 + 2 l its epilogue done"""
 import ctypes as C, os, sys
 import numpy as np, torch
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
