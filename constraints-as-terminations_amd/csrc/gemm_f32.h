@@ -81,7 +81,7 @@ __device__ __forceinline__ float elu_f(float z) {
   return z > 0.0f ? z : e;
 }
 
-#ifdef GEMM_TIMELINE   // tools/pair_timeline.hip: per-workgroup stamps [1] main loop start, [2] main loop end (shader clocks)
+#ifdef GEMM_TIMELINE   // tools/pair_timeline.hip: per-workgroup stamps of the main loop: [0] / [3] wall clock, [1] / [2] shader clock at its start / end
 __device__ unsigned long long* g_tl;
 #endif
 
@@ -280,7 +280,10 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   }
 
 #ifdef GEMM_TIMELINE
-  if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 1] = clock64();
+  if (threadIdx.x == 0) {
+    g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 0] = wall_clock64();
+    g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 1] = clock64();
+  }
 #endif
   // Two copies of the main loop: interior tiles whose contraction range is a whole number of slabs run one with
   // straight-line global loads (no guard, no branch: the compiler otherwise merges the guarded and the unguarded load
@@ -452,7 +455,10 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   else main_loop(std::false_type{});
 
 #ifdef GEMM_TIMELINE
-  if (threadIdx.x == 0) g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 2] = clock64();
+  if (threadIdx.x == 0) {
+    g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 2] = clock64();
+    g_tl[(blockIdx.x + gridDim.x * blockIdx.z) * 4 + 3] = wall_clock64();
+  }
 #endif
   // ---- epilogue.  acc[tm][tn][r] of lane: row = (r&3) + 8*(r>>2) + 4*h, col = l31 ----------
   if constexpr (EPI == EPI_BIAS_ELU_LDS) {

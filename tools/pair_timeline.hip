@@ -212,6 +212,53 @@ void peak(int blocks_per_cu, int iters) {
   CK(hipFree(clk));
 }
 
+// Round 4: shader clock and MFMA pace INSIDE the slab loops of the production paired launch (dW 128x128 x 32 splits first,
+// dX 64x128), from gemm_body's own stamps (wall clock + s_memtime at loop start / end of every workgroup).
+void pair_clock(Params pw, Params px) {
+  const int M = pw.Kc, splits = 32;
+  int per = (M + splits - 1) / splits;
+  per = (per + 15) / 16 * 16;
+  pw.splits = (M + per - 1) / per, pw.kc_per_split = per;
+  const int t0 = tiles_of<128, 128>(pw), n0 = t0 * pw.nets * pw.splits;
+  const int t1 = tiles_of<64, 128>(px), n1 = t1 * px.nets;
+  const size_t lds = std::max(gemm::smem_bytes<128, 128, false, false>(), gemm::smem_bytes<64, 128, true, false>());
+  auto kern = gemm::gemm_pair_kernel<128, 128, false, false, gemm::EPI_PARTIAL, 64, 128, true, false, gemm::EPI_MUL_DELU>;
+  const int grid = n0 + n1;
+  unsigned long long* tl;
+  CK(hipMalloc(&tl, (size_t)grid * 4 * 8));
+  CK(hipMemset(tl, 0, (size_t)grid * 4 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(gemm::g_tl), &tl, sizeof(tl)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) kern<<<grid, 256, lds>>>(pw, px, t0, n0, t1);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < 20; ++i) kern<<<grid, 256, lds>>>(pw, px, t0, n0, t1);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)grid * 4);
+  CK(hipMemcpy(h.data(), tl, h.size() * 8, hipMemcpyDeviceToHost));
+  auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+  for (int kind = 0; kind < 2; ++kind) {
+    std::vector<double> us, ghz, tpm;
+    const int lo = kind == 0 ? 0 : n0, hi = kind == 0 ? n0 : grid;
+    const double mfmas = kind == 0 ? (per / 16) * 32.0 : (px.Kc / 16) * 16.0;      // per wave: slabs x MFMAs per slab
+    for (int b = lo; b < hi; ++b) {
+      const double w = (h[4 * b + 3] - h[4 * b + 0]) * 0.01, t = (double)(h[4 * b + 2] - h[4 * b + 1]);
+      if (w <= 0) continue;
+      us.push_back(w), ghz.push_back(t / w / 1e3), tpm.push_back(t / mfmas);
+    }
+    printf("pair_clock %s workgroups: main loop %.1f us (median), shader clock %.3f GHz, %.0f MFMAs per wave = %.1f ticks each\n",
+           kind == 0 ? "dW (128x128, 32 slabs)" : "dX (64x128, 16 slabs)", med(us), med(ghz), mfmas, med(tpm));
+  }
+  printf("pair_clock: %.1f us per launch (20 back to back), %.1f TFLOP/s\n", ms * 1e3f / 20,
+         (2.0 * 2 * 2 * (double)M * 256 * 256) / (ms * 1e-3 / 20) * 1e-12);
+  CK(hipFree(tl));
+}
+
 int main() {
   peak(2, 2000);
   const int M = 16384, H = 256;
@@ -250,5 +297,6 @@ int main() {
     for (int n = 0; n < 2; ++n) pf.op[n].A = Hin[n], pf.op[n].B = W[n], pf.op[n].C = dX[n], pf.op[n].bias = bias;
     for (int r = 0; r < 3; ++r) fwd("forward 128x128", pf);
   }
+  pair_clock(pw, px);
   return 0;
 }
