@@ -1,4 +1,5 @@
-// Fused rollout step: everything between the simulator's state update and the next policy forward in TWO launches.
+// Fused rollout step: everything between the simulator's state update and the next policy forward in THREE launches
+// (two in rounds 2-3: the fold behind rollout_pre was a "last workgroup to arrive" tree inside that launch).
 //
 // The reference spends, per env step, ~15 eager launches + one host sync PER constraint term
 // (cat/constraint_manager.py:39-82,213-229), six launches + a nonzero() sync in CaTEnv.step (cat/cat_env.py:92-121),
@@ -8,8 +9,13 @@
 // latency bound (72-92 % of the wave cycles parked), so the step costs ten launch gaps.  Here:
 //
 //   rollout_pre   16-env tiles.  process_action, counters, terminations, raw reward; all constraint terms -> cstr;
-//                 per-workgroup column maxima and fp64 observation moments; the LAST workgroup to finish (device-scope
-//                 ticket) folds the partials in fixed order into the exchange buffer {colmax[K] | sum x, sum x^2 [2D]}.
+//                 per-workgroup column maxima and fp64 observation moments (one partial row per workgroup).
+//   rollout_fold  one workgroup per 16 columns folds the partial rows in fixed order into the exchange buffer
+//                 {colmax[K] | sum x, sum x^2 [2D]}.  Round 4: a launch boundary (~1.5 us) in place of two in-kernel
+//                 hand-shakes (arrive on a device-scope ticket, ~3.5 us coherent re-read of the partial rows, each):
+//                 1.58 -> 1.43 ms per 24-step rollout at cfg2 (profiles/r4_ab_rollout_fold_launch.txt).  The old tree
+//                 stays behind CATPPO_ROLLOUT_TREE=1; both orders are fixed, maxima are order independent, the fp64
+//                 moment sums differ in the last bit between the two (tests hold either against the oracle's bar).
 //   [env-sharded runs all-reduce the exchange buffer here: MAX for the maxima, SUM for the moments]
 //   rollout_post  32-env tiles.  Every workgroup derives the new running maxima (EMA) and the merged normaliser
 //                 statistics from the exchange buffer on its own (K + D values: cheaper than another launch), then
@@ -21,6 +27,7 @@
 // Arithmetic: identical statements in identical order to cat_step.hip / rms.hip / env_step.hip (this file is
 // compiled with -ffp-contract=off as well), so the termination masks stay bit-exact.
 #include "terms_eval.h"
+#include <cstdlib>
 #include "xwg.h"
 
 namespace {
@@ -74,6 +81,7 @@ struct PreArgs {
   const float4* sim_src;
   float4* sim_dst;
   int sim_row_q4;
+  int tree;                 // 1: fold the partial rows inside this launch (rounds 2-3); 0: rollout_fold_kernel does it
 };
 constexpr int kFoldGroup = 32;    // workgroups per first-level fold
 constexpr int kMaxPreBlocks = 1024;
@@ -265,6 +273,9 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
       }
     }
   }
+  // round 4: the partial rows are folded by a small launch of their own (rollout_fold_kernel, below) - the two
+  // hand-shakes of the in-launch tree cost more than a kernel boundary; a.tree keeps the tree for A/B
+  if (!a.tree) return;
   // ---- fold tree, two levels, no extra launch: the last workgroup of every group of 32 folds the group's partial rows,
   //      the last of those folds the group rows into the exchange buffer.  Every fold is at most 32 rows deep, and the
   //      order of every sum depends only on the grid size - not on which workgroup happens to arrive last.
@@ -293,6 +304,69 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
     block_fold<double>(a.osum_group, n_grp, 2 * D, 0.0, [](double x, double y) { return x + y; }, fold_lds,
                        [&](int c, double v) { a.x_sums[c] = v; });
   RL_TL(0, 7);
+}
+
+// Fold of rollout_pre's per-workgroup partial rows into the exchange record, as a launch of its own (round 4).  The
+// in-launch tree needed two "last workgroup to arrive" hand-shakes, each an arrive (atomic ticket) plus a ~3.5 us round
+// trip to the coherence point for the rows: ~11 us at the end of a 22.8 us launch; a kernel boundary inside the stream
+// costs ~1.5 us and these few workgroups a few us.  One workgroup per 16 columns of {K column maxima | 2 D moment sums};
+// thread (c, g): column c, rows g, g + 16, ... - every row of a pass requested before the first is used, sums in a fixed
+// order (thread: ascending rows; then the 16 row groups ascending through LDS) => bit-reproducible; maxima are exact in
+// any order.  The summation order of the fp64 moments differs from the tree's: same bars, other last bits.
+__global__ __launch_bounds__(256) void rollout_fold_kernel(const float* __restrict__ colmax_partial,
+                                                           const double* __restrict__ osum_partial, const int nblk,
+                                                           const int K, const int D2, float* __restrict__ x_colmax,
+                                                           double* __restrict__ x_sums) {
+  __shared__ double lds[256];
+  const int c16 = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + c16;            // [0, K): a maximum; [K16, K16 + D2): a moment sum (K16 = K rounded up to 16)
+  const int K16 = (K + 15) / 16 * 16;
+  const bool is_max = blockIdx.x * 16 < K16;
+  constexpr int kBatch = 16;
+  if (is_max) {
+    float m = -__builtin_inff();
+    if (col < K) {
+      for (int b0 = g; b0 < nblk; b0 += 16 * kBatch) {
+        float x[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const int b = b0 + 16 * j;
+          x[j] = colmax_partial[(int64_t)(b < nblk ? b : nblk - 1) * K + col];     // past the end: re-read, ignored
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j)
+          if (b0 + 16 * j < nblk) m = nanmax(m, x[j]);
+      }
+    }
+    reinterpret_cast<float*>(lds)[threadIdx.x] = m;
+    __syncthreads();
+    if (g == 0 && col < K) {
+      for (int gg = 1; gg < 16; ++gg) m = nanmax(m, reinterpret_cast<float*>(lds)[gg * 16 + c16]);
+      x_colmax[col] = (m < 1e-6f) ? 1e-6f : m;      // clamp(min=1e-6); NaN stays NaN like torch
+    }
+  } else {
+    const int sc = col - K16;
+    double a = 0.0;
+    if (sc < D2) {
+      for (int b0 = g; b0 < nblk; b0 += 16 * kBatch) {
+        double x[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const int b = b0 + 16 * j;
+          x[j] = osum_partial[(int64_t)(b < nblk ? b : nblk - 1) * D2 + sc];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j)
+          if (b0 + 16 * j < nblk) a += x[j];
+      }
+    }
+    lds[threadIdx.x] = a;
+    __syncthreads();
+    if (g == 0 && sc < D2) {
+      for (int gg = 1; gg < 16; ++gg) a += lds[gg * 16 + c16];
+      x_sums[sc] = a;
+    }
+  }
 }
 
 struct TermMetaS {
@@ -347,6 +421,46 @@ __device__ __forceinline__ void store_plane(void* p, int64_t i, float v, int f16
   else reinterpret_cast<float*>(p)[i] = v;
 }
 
+// new running maximum of column c (constraint_manager.py:58-61) from the exchange record(s) and the state of the previous
+// step (every workgroup of rollout_post_kernel, into LDS; the last one to arrive writes it back)
+__device__ __forceinline__ float derive_running_max(const PostArgs& a, int c) {
+  float m = a.x_colmax[c];
+  for (int w = 1; w < a.x_records; ++w)     // gathered records of the other ranks: MAX is exact and order independent
+    m = nanmax(m, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_colmax) + w * a.x_stride)[c]);
+  if (a.first_call) return m;
+  const float x = a.rm[c] * a.tau;           // rm.mul_(tau)
+  const float y = a.one_minus_tau * m;       // (1-tau) * cmax
+  return x + y;                              // .add_()
+}
+// merged observation normaliser of column c (cleanrl/ppo.py:48-62, the op order of rms.hip): new mean / variance
+__device__ __forceinline__ void derive_normaliser(const PostArgs& a, int c, float cnt, float nf, float tot, float* new_mean,
+                                                  float* new_var) {
+  const int D = a.D;
+  double sx = a.x_sums[c], sxx = a.x_sums[D + c];
+  for (int w = 1; w < a.x_records; ++w) {   // rank order: the same sums on every rank
+    const double* xs = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x_sums) + w * a.x_stride);
+    sx += xs[c], sxx += xs[D + c];
+  }
+  const double m = sx / a.obs_n;
+  double v = sxx / a.obs_n - m * m;
+  if (v < 0.0) v = 0.0;
+  const float bm = (float)m, bv = (float)v;
+  const float mean = a.obs_mean[c];
+  const float delta = bm - mean;
+  float t = delta * nf;
+  t = t / tot;
+  *new_mean = mean + t;
+  const float m_a = a.obs_var[c] * cnt;
+  const float m_b = bv * nf;
+  float d2 = delta * delta;
+  d2 = d2 * cnt;
+  d2 = d2 * nf;
+  d2 = d2 / tot;
+  float M2 = m_a + m_b;
+  M2 = M2 + d2;
+  *new_var = M2 / tot;
+}
+
 __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a, const TermMetaS meta) {
   extern __shared__ float smem[];
   __shared__ double red[2 * kMaxTerms * kPostRows];             // reset statistics per (term, env) of the tile
@@ -368,18 +482,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
   for (int c = threadIdx.x; c < K; c += kThreads) {
     int t = 0;
     while (t + 1 < nt && c >= s_off[t + 1]) ++t;
-    float m = a.x_colmax[c];
-    for (int w = 1; w < a.x_records; ++w)     // gathered records of the other ranks: MAX is exact and order independent
-      m = nanmax(m, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_colmax) + w * a.x_stride)[c]);
-    float r;
-    if (a.first_call) {
-      r = m;
-    } else {
-      const float x = a.rm[c] * a.tau;           // rm.mul_(tau)
-      const float y = a.one_minus_tau * m;       // (1-tau) * cmax
-      r = x + y;                                 // .add_()
-    }
-    col_rm[c] = r;
+    col_rm[c] = derive_running_max(a, c);
     col_dp[c] = meta.dp[t];
   }
   // ---- merged observation normaliser (cleanrl/ppo.py:48-62, the op order of rms.hip)
@@ -389,29 +492,8 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const float tot = cnt + nf;
     if (threadIdx.x == 0) s_tot = tot;
     for (int c = threadIdx.x; c < D; c += kThreads) {
-      double sx = a.x_sums[c], sxx = a.x_sums[D + c];
-      for (int w = 1; w < a.x_records; ++w) {   // rank order: the same sums on every rank
-        const double* xs = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x_sums) + w * a.x_stride);
-        sx += xs[c], sxx += xs[D + c];
-      }
-      const double m = sx / a.obs_n;
-      double v = sxx / a.obs_n - m * m;
-      if (v < 0.0) v = 0.0;
-      const float bm = (float)m, bv = (float)v;
-      const float mean = a.obs_mean[c];
-      const float delta = bm - mean;
-      float t = delta * nf;
-      t = t / tot;
-      const float new_mean = mean + t;
-      const float m_a = a.obs_var[c] * cnt;
-      const float m_b = bv * nf;
-      float d2 = delta * delta;
-      d2 = d2 * cnt;
-      d2 = d2 * nf;
-      d2 = d2 / tot;
-      float M2 = m_a + m_b;
-      M2 = M2 + d2;
-      const float new_var = M2 / tot;
+      float new_mean, new_var;
+      derive_normaliser(a, c, cnt, nf, tot, &new_mean, &new_var);
       s_mean[c] = new_mean;
       s_var[c] = new_var;
       s_den[c] = sqrtf(new_var + a.obs_eps);
@@ -512,6 +594,9 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     }
   }
   RL_TL(1, 2);
+  // (round 4 measured this tail as a one-workgroup launch of its own, like rollout_fold_kernel behind the pre kernel:
+  // 1.51 against 1.44 ms per rollout - its work is a chain of three dependent memory round trips either way, and here
+  // only ONE hand-shake stands in front of it, not two - so it stays with the last workgroup to arrive)
   const bool lastp = last_block_arrives(a.ticket, gridDim.x);
   RL_TL(1, 3);
   if (!lastp) return;
@@ -640,9 +725,20 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
   p.x_colmax = static_cast<float*>(a->xchg);
   p.x_sums = reinterpret_cast<double*>(static_cast<char*>(a->xchg) + xchg_sum_offset(a->K));
   p.ticket = ctx->tickets + catppo_ctx::kTicketPre;      // [0] launch, [1 .. 32] groups
+  // CATPPO_ROLLOUT_TREE=1: fold the partial rows inside the launch (two-level tree of rounds 2-3) instead of by
+  // rollout_fold_kernel - A/B switch
+  static const bool tree = [] { const char* e = getenv("CATPPO_ROLLOUT_TREE"); return e && e[0] == '1'; }();
+  p.tree = tree ? 1 : 0;
   hipLaunchKernelGGL(rollout_pre_kernel, dim3((unsigned)nblk), dim3(kThreads), lds, static_cast<hipStream_t>(stream), tab,
                      p);
   CATPPO_CHECK_LAUNCH(ctx);
+  if (!tree) {
+    const int K16 = (a->K + 15) / 16 * 16, D2 = a->obs_raw != nullptr ? 2 * a->D : 0;
+    hipLaunchKernelGGL(rollout_fold_kernel, dim3((unsigned)((K16 + D2 + 15) / 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), (const float*)cpart, (const double*)opart, (int)nblk, a->K, D2,
+                       p.x_colmax, p.x_sums);
+    CATPPO_CHECK_LAUNCH(ctx);
+  }
   return CATPPO_OK;
 }
 
