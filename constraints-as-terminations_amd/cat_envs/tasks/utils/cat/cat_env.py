@@ -300,8 +300,8 @@ class CaTEnv:
                 and cm.can_fuse_rollout(native.get(self.device)))
 
     def step_into(self, action: torch.Tensor, sink):
-        """``step`` with everything after the simulator update fused into two launches (catppo_rollout_pre /
-        catppo_rollout_post), including the consumer's part: ``sink`` (see ``cleanrl.ppo.RolloutSink``) names the
+        """``step`` with everything after the simulator update fused into two calls (catppo_rollout_pre /
+        catppo_rollout_post: three launches), including the consumer's part: ``sink`` (see ``cleanrl.ppo.RolloutSink``) names the
         rollout-buffer rows of this step and the observation normaliser, so rewards / dones / time-outs and the
         normalised next observation are written where PPO wants them.  Same return tuple as ``step``; ``extras["log"]``
         is the manager's view dict of the ring slot written by this step, the curriculum scalars ride in

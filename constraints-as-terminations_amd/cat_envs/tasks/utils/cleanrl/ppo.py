@@ -13,7 +13,7 @@ runs in libcatppo.so (hand-written HIP, see include/catppo.h):
                                                                per 32-row workgroup - else 3 GEMM launches + head:
                                                                actions/logprobs/values[step]; Philox action noise inside)
                    env.step_into -> catppo_rollout_pre/_post  (simulator state advance, terms, CaT, resets, buffer rows,
-                                                               obs normaliser: 2 launches; a foreign env takes the
+                                                               obs normaliser: 3 launches; a foreign env takes the
                                                                unfused calls)
     after rollout  catppo_value, catppo_gae, 2x (catppo_rms_update + catppo_rms_normalize)
     epoch          catppo_ppo_gather_ex                       (keyed on-device permutation, no index array)

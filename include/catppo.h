@@ -524,7 +524,8 @@ typedef struct catppo_rollout_step {
 } catppo_rollout_step;
 uint64_t catppo_rollout_xchg_bytes(int K, int D);
 uint64_t catppo_rollout_step_sizeof(void);   /* sizeof(catppo_rollout_step): lets a binding check its struct layout */
-/* phase 1 and phase 2 (call both back to back on one GPU; all-reduce xchg in between when env-sharded:
+/* phase 1 (two launches: the per-tile kernel and the fold of its partial rows into `xchg`) and phase 2 (one launch); call
+ * both back to back on one GPU; all-reduce xchg in between when env-sharded:
  * floats [0,K) with MAX, doubles at byte offset catppo_rollout_xchg_sum_offset(K) [2*D] with SUM) */
 uint64_t catppo_rollout_xchg_sum_offset(int K);
 int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);

@@ -248,3 +248,14 @@ def test_row_resident_forward_every_slab_count_of_the_first_layer(tmp_path, D):
     assert np.abs(outs[1]["grad"]).max() > 0
     np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
     np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
+
+
+def test_in_launch_fold_tree_of_the_env_step_still_holds_the_fused_step_tests():
+    """The default since round 4 folds rollout_pre's partial rows in a launch of its own (rollout_fold_kernel), which the
+    fused-vs-unfused tests of test_gpu_r2_features.py exercise as they are; the rounds 2-3 tree inside the launch
+    (CATPPO_ROLLOUT_TREE=1, read once per process) is held to the same tests here."""
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_gpu_r2_features.py"), "-k", "fused_rollout"],
+                       env=dict(os.environ, CATPPO_ROLLOUT_TREE="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+    assert "2 passed" in r.stdout, r.stdout[-500:]
