@@ -69,6 +69,15 @@ def init_native_comm(nat, group=None) -> bool:
         failed = [(i, v) for i, v in enumerate(votes) if v is not None]
         if failed and err is None:
             nat.comm_destroy()
+    if not failed:
+        # (3) known-answer pass of every collective the data path uses, on this communicator: the first real N-rank run
+        # must not also be the first time anybody looks at what these calls return
+        err = _selfcheck(nat, r, w)
+        votes = [None] * w
+        dist.all_gather_object(votes, err, group=group)
+        failed = [(i, v) for i, v in enumerate(votes) if v is not None]
+        if failed:
+            nat.comm_destroy()
     if failed:
         _native_error = "; ".join(f"rank {i}: {v}" for i, v in failed)
         if r == 0:
@@ -78,6 +87,59 @@ def init_native_comm(nat, group=None) -> bool:
         return False
     _native = nat
     return True
+
+
+#: seconds the known-answer pass may take before the communicator is declared unusable (first RCCL call: lazy channel set-up)
+_SELFCHECK_TIMEOUT_S = float(os.environ.get("CATPPO_COMM_SELFCHECK_TIMEOUT", "180"))
+
+
+def _selfcheck(nat, r: int, w: int):
+    """SUM (fp32, fp64, fp16), MAX, broadcast and all-gather with closed-form answers on the fresh communicator; returns
+    None or what went wrong.  Waits with a deadline (stream query, no blocking synchronise): a collective that never
+    completes is reported instead of hanging the job before its first line of output."""
+    import time
+    try:
+        dev = nat.device
+        n = 1027                                                   # not a multiple of anything RCCL slices by
+        i = torch.arange(n, device=dev, dtype=torch.float64)
+        s32 = ((i % 7) + 1 + r).float()
+        s64 = (i + 1) * (r + 1) + 1e-9 * r
+        s16 = torch.full((n,), float(r % 3), device=dev, dtype=torch.float16)
+        m32 = ((i * 31 + 17 * r) % 101).float()
+        b32 = torch.full((n,), float(r + 5), device=dev)
+        rec = torch.full((24,), r, device=dev, dtype=torch.uint8)
+        got = torch.empty(24 * w, device=dev, dtype=torch.uint8)
+        nat.allreduce(s32, 0), nat.allreduce(s64, 0), nat.allreduce(s16, 0), nat.allreduce(m32, 1)
+        nat.broadcast(b32, w - 1), nat.allgather(rec, got)
+        if dev.type == "cuda":
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            t0 = time.monotonic()
+            while not done.query():
+                if time.monotonic() - t0 > _SELFCHECK_TIMEOUT_S:
+                    return f"known-answer collectives did not complete within {_SELFCHECK_TIMEOUT_S:.0f} s"
+                time.sleep(0.002)
+        ranks = torch.arange(w, device=dev, dtype=torch.float64)
+        exp32 = (w * ((i % 7) + 1) + ranks.sum()).float()
+        exp64 = (i + 1) * (ranks + 1).sum()
+        exp16 = float(sum(k % 3 for k in range(w)))
+        expm = torch.stack([(i * 31 + 17 * k) % 101 for k in range(w)]).max(0).values.float()
+        bad = []
+        if not torch.equal(s32, exp32):
+            bad.append("SUM fp32")
+        if not torch.allclose(s64, exp64, rtol=1e-12, atol=1e-8 * w):
+            bad.append("SUM fp64")
+        if not bool((s16.float() == exp16).all()):
+            bad.append("SUM fp16")
+        if not torch.equal(m32, expm):
+            bad.append("MAX fp32")
+        if not bool((b32 == float(w - 1 + 5)).all()):
+            bad.append("broadcast")
+        if not torch.equal(got.view(w, 24), torch.arange(w, device=dev, dtype=torch.uint8)[:, None].expand(w, 24)):
+            bad.append("all-gather")
+        return ("wrong result of " + ", ".join(bad)) if bad else None
+    except RuntimeError as e:
+        return str(e)
 
 
 def native_comm_error():

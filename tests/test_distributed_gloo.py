@@ -141,9 +141,23 @@ def _worker(rank, world, port, out_dir):
     #          torch.distributed and know why; then rank 0 cannot even make an id -> same outcome, nobody hangs
     class _Nat:
         comm_world = 0
+        device = torch.device("cpu")
 
-        def __init__(self, fail_id=False, fail_init=False):
+        def __init__(self, fail_id=False, fail_init=False, wrong_max=False):
             self.fail_id, self.fail_init, self.destroyed, self.init_calls = fail_id, fail_init, False, 0
+            self.wrong_max = wrong_max
+
+        # the collectives of a communicator that did come up (here: carried by the test's gloo group)
+        def allreduce(self, t, op=0):
+            dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+            if op == 1 and self.wrong_max:
+                t[3] += 1.0
+
+        def broadcast(self, t, root=0):
+            dist.broadcast(t, src=root)
+
+        def allgather(self, send, recv):
+            dist.all_gather_into_tensor(recv, send)
 
         def comm_unique_id(self):
             if self.fail_id:
@@ -176,6 +190,16 @@ def _worker(rank, world, port, out_dir):
     nat_c = _Nat(fail_id=(rank == 1))
     assert parallel.init_native_comm(nat_c) is False and "rank 1" in parallel.native_comm_error()
     assert nat_c.init_calls == 0 and not nat_c.destroyed
+    # a communicator that comes up but returns a wrong MAX on one rank (known-answer pass after the set-up, round 4):
+    # both ranks leave it again and say which collective on which rank
+    nat_d = _Nat(wrong_max=(rank == 1))
+    assert parallel.init_native_comm(nat_d) is False and nat_d.destroyed
+    assert parallel.native_comm_error() == "rank 1: wrong result of MAX fp32", parallel.native_comm_error()
+    # ... and one whose collectives all answer correctly is taken
+    nat_e = _Nat()
+    assert parallel.init_native_comm(nat_e) is True and parallel.native_comm_active()
+    parallel.shutdown_native_comm()
+    assert nat_e.destroyed and not parallel.native_comm_active()
     assert parallel.gather_counts(50 + rank) == [50, 51]
     chk = torch.ones(1)
     parallel.allreduce_sum_(chk)                   # the fallback transport still works
