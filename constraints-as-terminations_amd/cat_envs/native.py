@@ -145,6 +145,10 @@ _SIGNATURES = {
     "catppo_ppo_minibatch_grad_packed": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp,
                                                    _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catppo_clip_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _f64, _i64, _vp]),
+    # ABI 0.4: gradient + clip + Adam of a single process in one call
+    "catppo_ppo_minibatch_step_packed": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp,
+                                                   _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f64, _f64,
+                                                   _f64, _vp, _vp]),
     # ---- ABI 0.2
     "catppo_iter_init": (C.c_int, [_vp, _vp, _u64, _f64, _vp]),
     "catppo_iter_begin": (C.c_int, [_vp, _vp, _f64, _i64, C.c_int, _vp]),
@@ -545,6 +549,16 @@ class Native:
         self._ok(self.lib.catppo_ppo_minibatch_grad_packed(
             self.h, C.byref(shape), C.byref(hp), _p(params), _p(x_mb), _p(act_mb), _p(scal_mb), _p(adv_part_mb),
             int(M), _p(vrms_mean), _p(vrms_var), _p(adv_stats), _p(grad), _p(diag), self._stream()))
+
+    def ppo_minibatch_step_packed(self, shape, hp: PpoHparams, params, x_mb, act_mb, scal_mb, adv_part_mb, M,
+                                  vrms_mean, vrms_var, adv_stats, grad, diag, exp_avg, exp_avg_sq, max_grad_norm,
+                                  beta1, beta2, eps, st):
+        """``ppo_minibatch_grad_packed`` + ``clip_adam_dev`` in one call (single process: nothing reduces the gradient
+        in between); the fold launches emit the squared norm the clip needs"""
+        self._ok(self.lib.catppo_ppo_minibatch_step_packed(
+            self.h, C.byref(shape), C.byref(hp), _p(params), _p(x_mb), _p(act_mb), _p(scal_mb), _p(adv_part_mb),
+            int(M), _p(vrms_mean), _p(vrms_var), _p(adv_stats), _p(grad), _p(diag), _p(exp_avg), _p(exp_avg_sq),
+            f32(max_grad_norm), float(beta1), float(beta2), float(eps), _p(st), self._stream()))
 
     def clip_adam(self, params, grad, exp_avg, exp_avg_sq, n_flat, max_grad_norm, lr, beta1, beta2, eps, step):
         self._ok(self.lib.catppo_clip_adam(self.h, _p(params), _p(grad), _p(exp_avg), _p(exp_avg_sq), int(n_flat),

@@ -19,6 +19,7 @@ runs in libcatppo.so (hand-written HIP, see include/catppo.h):
     epoch          catppo_ppo_gather_ex                       (keyed on-device permutation, no index array)
     minibatch      catppo_ppo_minibatch_grad_packed  [catppo_allreduce: RCCL SUM of the flat gradient]
                    catppo_clip_adam_dev                       (lr / step count from the device state)
+                   single process: both in one call, catppo_ppo_minibatch_step_packed (6 launches instead of 7)
     [KL-adaptive]  catppo_kl_mean [catppo_allreduce] catppo_kl_adaptive_lr   after every epoch, no host sync
 The update phase is replayed from a hipGraph (``graph_update``; collectives of an env-sharded run included, with a
 reported eager fallback when the capture fails).
@@ -448,6 +449,14 @@ class PPOTrainer:
         self.grad_overlap = False
         if parallel.active() and parallel.native_comm_active():
             self.grad_overlap = self.nat.set_grad_overlap(bool(go))
+        # single process: an optimiser step is ONE library call (catppo_ppo_minibatch_step_packed) whose fold launches
+        # emit the squared gradient norm of the clip - the launch that re-read the gradient for it is gone.  Not with
+        # exchange points on (the gradient all-reduce sits between fold and clip) nor with the side-stream experiment.
+        ocs = getattr(c, "one_call_step", None)
+        if os.environ.get("CATPPO_ONE_CALL_STEP") is not None:
+            ocs = os.environ["CATPPO_ONE_CALL_STEP"] == "1"
+        self.one_call_step = (True if ocs is None else bool(ocs)) and not parallel.active() and \
+            os.environ.get("CATPPO_SIDE_STREAM", "0") != "1"
         self._graph_id = None
         self._eager_updates_left = 1 if parallel.active() else 0
         self.graph_nodes = 0
@@ -604,6 +613,13 @@ class PPOTrainer:
                 start, m = k * M, self._mb_rows[k]
                 self.hp.inv_global_batch = 1.0 / self._mb_rows_global[k]     # mean over the GLOBAL minibatch
                 adv_stats = self._adv_stats_all[epoch * n_mb + k] if exact_adv else None
+                if self.one_call_step:
+                    # single process: gradient, clip and Adam in one call (the fold launches emit the squared norm)
+                    nat.ppo_minibatch_step_packed(a.shape, self.hp, a.flat, self._x_g[start:], self._act_g[start:],
+                                                  self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
+                                                  vmean, vvar, adv_stats, self.grad, self.diag, self.exp_avg,
+                                                  self.exp_avg_sq, c.max_grad_norm, 0.9, 0.999, 1e-5, self.state)
+                    continue
                 nat.ppo_minibatch_grad_packed(a.shape, self.hp, a.flat, self._x_g[start:], self._act_g[start:],
                                               self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
                                               vmean, vvar, adv_stats, self.grad, self.diag)

@@ -81,11 +81,12 @@ struct MlpWs {
   float* bpart[CATPPO_MAX_HIDDEN];   // split-K partial bias gradients per layer
   float* head_w;           // [nb_head][(A+1)*HL]
   float* head_s;           // [nb_head][kHeadScalars]
-  double* norm_part;       // [kNormBlocks]
+  double* norm_part;       // [kNormSlots]: squared-norm partials emitted by the launches that fold the gradient (NormEmit)
   uint64_t bytes;
 };
 constexpr int kHeadDiag = 8;
 constexpr int kNormBlocks = 256;
+constexpr int kNormSlots = 256 * 24;     // 256 workgroups per segment x kMaxSegs (static_assert at its definition)
 inline int head_scalars(int A) { return 2 * A + 1 + kHeadDiag; }  // db4a[A], db4c, dlogstd[A], diag[8]
 
 // split-K count cap: the partial sums are written once and re-read by the fold, so a layer may use as many
@@ -132,7 +133,7 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
     w->head_w = (float*)take(sizeof(float) * nbh * (A + 1) * s->hidden[nl - 1]);
     w->head_s = (float*)take(sizeof(float) * nbh * head_scalars(A));
   }
-  w->norm_part = (double*)take(sizeof(double) * kNormBlocks);
+  w->norm_part = (double*)take(sizeof(double) * kNormSlots);
   w->bytes = used;
   return ok;
 }
@@ -1731,8 +1732,11 @@ __device__ __forceinline__ float4 seg_sum4(const float* __restrict__ src, int64_
 }
 
 // one workgroup's share of one segment: workgroup bx of nbx walks the segment's elements (sm: 1024 floats of LDS)
-__device__ __forceinline__ void seg_reduce_body(const Seg sg, const int bx, const int nbx, float* __restrict__ sm,
-                                                const float ent_coef, const float vf_coef) {
+// Returns the fp64 sum of squares of the gradient elements THIS thread wrote (mode 0 only): the launches that fold the
+// gradient can emit the squared-norm partials of the clip on the way (NormEmit below).
+__device__ __forceinline__ double seg_reduce_body(const Seg sg, const int bx, const int nbx, float* __restrict__ sm,
+                                                  const float ent_coef, const float vf_coef) {
+  double ss = 0.0;
   // few wide partials (split-K): 4 part groups x 64 lanes; many narrow ones (head): 16 x 16
   const int G = sg.n_parts >= 128 ? 16 : 4;
   const int EL = 256 / G;
@@ -1756,10 +1760,14 @@ __device__ __forceinline__ void seg_reduce_body(const Seg sg, const int bx, cons
           a.x += y.x, a.y += y.y, a.z += y.z, a.w += y.w;
         }
         *reinterpret_cast<float4*>(sg.dst + e) = a;
+        ss += (double)a.x * (double)a.x;
+        ss += (double)a.y * (double)a.y;
+        ss += (double)a.z * (double)a.z;
+        ss += (double)a.w * (double)a.w;
       }
       __syncthreads();
     }
-    return;
+    return ss;
   }
   for (int64_t e0 = (int64_t)bx * EL; e0 < sg.count; e0 += (int64_t)nbx * EL) {
     const int64_t e = e0 + el;
@@ -1779,6 +1787,7 @@ __device__ __forceinline__ void seg_reduce_body(const Seg sg, const int bx, cons
     if (g == 0 && e < sg.count) {
       if (sg.mode == 0) {
         sg.dst[e] = a;
+        ss += (double)a * (double)a;
       } else {
         // diagnostics block {pg, v, ent, loss, kl, old_kl, clipfrac, count} (count = 8 <= EL: one block)
         float v = a * sg.scale;
@@ -1789,11 +1798,50 @@ __device__ __forceinline__ void seg_reduce_body(const Seg sg, const int bx, cons
     }
     __syncthreads();
   }
+  return ss;
 }
 
-__global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef) {
+// The clip of an optimiser step needs ||grad||^2 (cleanrl/ppo.py:354, clip_grad_norm_): a launch of its own that
+// re-reads the gradient the fold launches have just written - 5 us per step for 1.2 MB.  With NormEmit.part set, every
+// workgroup that folds a piece of the gradient also writes the fp64 sum of squares of that piece into its own slot
+// (fixed slot per workgroup => the final sum has a fixed order), and one thread of the last fold launch advances the
+// Adam step count and prepares the bias corrections (what sqnorm_partial_step_kernel does beside its loads).
+// catppo_ppo_minibatch_step_packed then goes straight to the Adam launch.
+struct NormEmit {
+  double* part = nullptr;            // [kNormSlots]; nullptr: off
+  catppo_iter_state* st = nullptr;
+  double beta1 = 0.0, beta2 = 0.0;
+  int n_slots = 0;                   // slots written so far by the launches of this step (host side)
+};
+static_assert(kNormSlots >= 256 * kMaxSegs, "one squared-norm slot per fold workgroup");
+
+__device__ __forceinline__ void emit_norm_slot(double ss, double* __restrict__ slot, float* __restrict__ sm) {
+  ss = wave_sum_d(ss);
+  double* d = reinterpret_cast<double*>(sm);
+  __syncthreads();                   // sm is free (seg_reduce_body ends behind a barrier; belt and braces)
+  if ((threadIdx.x & 63) == 0) d[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = (d[0] + d[1]) + (d[2] + d[3]);
+}
+
+// torch.optim.Adam: bias_correction = 1 - beta ** step (Python doubles), step_size = lr / bias_correction1
+__device__ __forceinline__ void adam_advance_step(catppo_iter_state* __restrict__ st, double beta1, double beta2) {
+  const int64_t step_i = st->adam_step + 1;
+  const double step = (double)step_i;
+  const double bc1 = 1.0 - pow(beta1, step);
+  const double bc2 = 1.0 - pow(beta2, step);
+  st->adam_step = step_i;
+  st->adam_step_size = (float)(st->lr / bc1);
+  st->adam_bc2_sqrt = (float)sqrt(bc2);
+}
+
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float ent_coef, float vf_coef,
+                                                         double* __restrict__ norm_slots, catppo_iter_state* st,
+                                                         double beta1, double beta2) {
   __shared__ __attribute__((aligned(16))) float sm[1024];
-  seg_reduce_body(t.s[blockIdx.y], blockIdx.x, gridDim.x, sm, ent_coef, vf_coef);
+  if (st != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 64) adam_advance_step(st, beta1, beta2);
+  const double ss = seg_reduce_body(t.s[blockIdx.y], blockIdx.x, gridDim.x, sm, ent_coef, vf_coef);
+  if (norm_slots != nullptr) emit_norm_slot(ss, norm_slots + blockIdx.y * gridDim.x + blockIdx.x, sm);
 }
 
 // The first layer's weight-gradient GEMM and the fold of every OTHER layer's partials in one launch (round 4).  dW_0 is
@@ -1804,7 +1852,8 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const SegTable t, float
 // (launch order first: they are resident from the start), the rest fold: kFoldX workgroups per segment.
 constexpr int kFoldX = 256;
 __global__ __launch_bounds__(256) void dw_fold_kernel(const gemm::Params p, const SegTable t, const int gemm_tiles,
-                                                      const int n_gemm, float ent_coef, float vf_coef) {
+                                                      const int n_gemm, float ent_coef, float vf_coef,
+                                                      double* __restrict__ norm_slots) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.x;
   if (b < n_gemm) {
@@ -1812,7 +1861,8 @@ __global__ __launch_bounds__(256) void dw_fold_kernel(const gemm::Params p, cons
     gemm::gemm_body<64, 64, false, false, gemm::EPI_PARTIAL>(p, id.tile, id.bz, smem);
   } else {
     const int f = b - n_gemm;
-    seg_reduce_body(t.s[f / kFoldX], f % kFoldX, kFoldX, smem, ent_coef, vf_coef);
+    const double ss = seg_reduce_body(t.s[f / kFoldX], f % kFoldX, kFoldX, smem, ent_coef, vf_coef);
+    if (norm_slots != nullptr) emit_norm_slot(ss, norm_slots + f, smem);
   }
 }
 
@@ -2174,7 +2224,8 @@ namespace {
 // {old log-prob, advantage, normalised return, normalised value}, adv_part [nbg][2] fp64 advantage moments
 int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_mlp_layout& L, MlpWs& w,
                         const catppo_ppo_hparams* hp, const float* params, int64_t M, const float* vrms_mean,
-                        const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s);
+                        const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s,
+                        NormEmit* ne = nullptr);
 }  // namespace
 
 extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape* shape,
@@ -2267,7 +2318,8 @@ extern "C" int catppo_ppo_minibatch_grad_packed(catppo_ctx* ctx, const catppo_ml
 namespace {
 int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_mlp_layout& L, MlpWs& w,
                         const catppo_ppo_hparams* hp, const float* params, int64_t M, const float* vrms_mean,
-                        const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s) {
+                        const float* vrms_var, const float* adv_stats, float* grad, float* diag, hipStream_t s,
+                        NormEmit* ne) {
   const int nl = shape->n_hidden, A = shape->act_dim, HL = shape->hidden[nl - 1];
   const int nbg = (int)cdiv64(M, kGatherRows);
   // small minibatches (env-sharded runs: 2048 samples per rank): 16-row tiles double the workgroup count of a launch
@@ -2404,6 +2456,10 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   // catppo_set_grad_overlap + a communicator: fold and all-reduce the gradient in per-layer buckets on the side stream
   // while the backward launches of the layers below run on `s` (see the end of the layer loop)
   const bool overlap = !fork && ctx->grad_overlap && ctx->comm != nullptr;
+  if (ne != nullptr && (fork || overlap))
+    return catppo_fail(ctx, CATPPO_E_ARG, "%s: the one-call optimiser step cannot run with the side-stream weight "
+                       "gradients or the gradient buckets (something reduces the gradient between fold and clip)", __func__);
+  if (ne != nullptr) ne->n_slots = 0;
   const int bf16 = shape->mfma_bf16;   // 0 fp32 MFMA, 1 bf16 operands, 2 split-bf16 (bf16x3)
   hipStream_t side = fork ? ctx->side : s;
 #define CATPPO_HIP_OK(call)                                                                          \
@@ -2473,8 +2529,9 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       constexpr size_t lds = gemm::smem_bytes<64, 64, false, false>();
       static_assert(lds >= 4096, "the fold workgroups use 1024 floats of the same allocation");
       hipLaunchKernelGGL(dw_fold_kernel, dim3((unsigned)(n_gemm + kFoldX * segs.n)), dim3(256), lds, s, pw, segs, t64, n_gemm,
-                         hp->ent_coef, hp->vf_coef);
+                         hp->ent_coef, hp->vf_coef, ne ? ne->part + ne->n_slots : (double*)nullptr);
       CATPPO_CHECK_LAUNCH(ctx);
+      if (ne) ne->n_slots += kFoldX * segs.n;
       segs.n = 0;        // folded; what is added below (this layer's own partials) goes to the final fold launch
     } else if (!pair) {
       launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
@@ -2532,7 +2589,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
         CATPPO_HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork[l], 0));
       }
-      hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, bs, segs, hp->ent_coef, hp->vf_coef);
+      hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, bs, segs, hp->ent_coef, hp->vf_coef,
+                         (double*)nullptr, (catppo_iter_state*)nullptr, 0.0, 0.0);
       CATPPO_CHECK_LAUNCH(ctx);
       segs.n = 0;
       int64_t off[3], cnt[3];
@@ -2554,8 +2612,11 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   }
   if (overlap) return CATPPO_OK;      // `s` has joined the side stream in front of the last bucket
   // every split-K / head partial of the minibatch is folded into the flat gradient by one launch
-  hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef);
+  hipLaunchKernelGGL(seg_reduce_kernel, dim3(256, segs.n), dim3(256), 0, side, segs, hp->ent_coef, hp->vf_coef,
+                     ne ? ne->part + ne->n_slots : (double*)nullptr, ne ? ne->st : (catppo_iter_state*)nullptr,
+                     ne ? ne->beta1 : 0.0, ne ? ne->beta2 : 0.0);
   CATPPO_CHECK_LAUNCH(ctx);
+  if (ne) ne->n_slots += 256 * segs.n;
   if (fork) {
     CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, side));
     CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
@@ -2603,15 +2664,7 @@ __global__ __launch_bounds__(256) void sqnorm_partial_step_kernel(const float* _
   // (clip_adam_dev_kernel) while everybody else is waiting for their gradient loads: two double-precision pow() that
   // used to sit at the head of every workgroup of the Adam launch.
   // torch.optim.Adam: bias_correction = 1 - beta ** step (Python doubles), step_size = lr / bias_correction1
-  if (blockIdx.x == 0 && threadIdx.x == 64) {
-    const int64_t step_i = st->adam_step + 1;
-    const double step = (double)step_i;
-    const double bc1 = 1.0 - pow(beta1, step);
-    const double bc2 = 1.0 - pow(beta2, step);
-    st->adam_step = step_i;
-    st->adam_step_size = (float)(st->lr / bc1);
-    st->adam_bc2_sqrt = (float)sqrt(bc2);
-  }
+  if (blockIdx.x == 0 && threadIdx.x == 64) adam_advance_step(st, beta1, beta2);
   double a = sqnorm_of_thread(g, n);
   a = wave_sum_d(a);
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
@@ -2625,17 +2678,39 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(float* __restrict__ 
                                                             float max_norm, double beta1, double beta2, float eps,
                                                             const catppo_iter_state* __restrict__ st) {
   __shared__ float s_coef;
-  if (threadIdx.x < 64) {
-    double a = 0.0;
-    for (int b = threadIdx.x; b < n_part; b += 64) a += norm_part[b];
-    a = wave_sum_d(a);
+  if (n_part <= kNormBlocks) {
+    if (threadIdx.x < 64) {
+      double a = 0.0;
+      for (int b = threadIdx.x; b < n_part; b += 64) a += norm_part[b];
+      a = wave_sum_d(a);
+      if (threadIdx.x == 0) {
+        const float total = (float)sqrt(a);
+        const float c = max_norm / (total + 1e-6f);
+        s_coef = c > 1.0f ? 1.0f : c;
+      }
+    }
+  } else {
+    // the slots of the fold launches (one per fold workgroup, a few thousand): all four waves, eight requests in
+    // flight per thread, fixed order
+    __shared__ double s_w[4];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int b = threadIdx.x;
+    for (; b + 7 * 256 < n_part; b += 8 * 256) {
+      const double x0 = norm_part[b], x1 = norm_part[b + 256], x2 = norm_part[b + 512], x3 = norm_part[b + 768];
+      const double x4 = norm_part[b + 1024], x5 = norm_part[b + 1280], x6 = norm_part[b + 1536], x7 = norm_part[b + 1792];
+      a0 += x0, a1 += x1, a2 += x2, a3 += x3, a0 += x4, a1 += x5, a2 += x6, a3 += x7;
+    }
+    for (; b < n_part; b += 256) a0 += norm_part[b];
+    double a = wave_sum_d((a0 + a1) + (a2 + a3));
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+    __syncthreads();
     if (threadIdx.x == 0) {
-      const float total = (float)sqrt(a);
+      const float total = (float)sqrt((s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
       const float c = max_norm / (total + 1e-6f);
       s_coef = c > 1.0f ? 1.0f : c;
     }
   }
-  const float step_size = st->adam_step_size, bc2_sqrt = st->adam_bc2_sqrt;   // sqnorm_partial_step_kernel wrote them
+  const float step_size = st->adam_step_size, bc2_sqrt = st->adam_bc2_sqrt;   // the launch in front of this one wrote them
   __syncthreads();
   const AdamCoef c{s_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, step_size, bc2_sqrt};
   adam_all(p, g, m, v, n, c);
@@ -2660,6 +2735,40 @@ extern "C" int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad,
   if (nblk > 1024) nblk = 1024;
   hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(nblk), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq, n_flat,
                      (const double*)part, nb, max_grad_norm, beta1, beta2, (float)eps,
+                     (const catppo_iter_state*)state);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+// One optimiser step of a single process in one call (ABI 0.4): catppo_ppo_minibatch_grad_packed + catppo_clip_adam_dev
+// with the squared gradient norm emitted by the fold launches (NormEmit) instead of a launch that re-reads the gradient.
+extern "C" int catppo_ppo_minibatch_step_packed(catppo_ctx* ctx, const catppo_mlp_shape* shape,
+                                                const catppo_ppo_hparams* hp, float* params, const float* x_mb,
+                                                const float* act_mb, const float* scal_mb, const double* adv_part_mb,
+                                                int64_t M, const float* vrms_mean, const float* vrms_var,
+                                                const float* adv_stats, float* grad, float* diag, float* exp_avg,
+                                                float* exp_avg_sq, float max_grad_norm, double beta1, double beta2,
+                                                double eps, catppo_iter_state* state, void* stream) {
+  catppo_mlp_layout L;
+  MlpWs w{};
+  if (int rc = mlp_prologue(ctx, shape, M, true, &L, &w, __func__)) return rc;
+  CATPPO_CHECK_ARG(ctx, hp && params && x_mb && act_mb && scal_mb && adv_part_mb && vrms_mean && vrms_var && grad &&
+                            diag && exp_avg && exp_avg_sq && state);
+  CATPPO_CHECK_ARG(ctx, !hp->adv_stats_external || adv_stats != nullptr);
+  CATPPO_CHECK_ARG(ctx, (reinterpret_cast<uintptr_t>(x_mb) & 15) == 0);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  w.xmb = const_cast<float*>(x_mb), w.act = const_cast<float*>(act_mb), w.scal = const_cast<float*>(scal_mb);
+  w.adv_part = const_cast<double*>(adv_part_mb);
+  NormEmit ne;
+  ne.part = w.norm_part, ne.st = state, ne.beta1 = beta1, ne.beta2 = beta2;
+  if (int rc = minibatch_grad_core(ctx, shape, L, w, hp, params, M, vrms_mean, vrms_var, adv_stats, grad, diag, s, &ne))
+    return rc;
+  if (ne.n_slots < 1 || ne.n_slots > kNormSlots)
+    return catppo_fail(ctx, CATPPO_E_ARG, "%s: %d squared-norm slots", __func__, ne.n_slots);
+  int nblk = (int)cdiv64(L.n_flat, 256 * 4);
+  if (nblk > 1024) nblk = 1024;
+  hipLaunchKernelGGL(clip_adam_dev_kernel, dim3(nblk), dim3(256), 0, s, params, grad, exp_avg, exp_avg_sq,
+                     (int64_t)L.n_flat, (const double*)ne.part, ne.n_slots, max_grad_norm, beta1, beta2, (float)eps,
                      (const catppo_iter_state*)state);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;

@@ -390,6 +390,19 @@ int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad, float* exp
                          int64_t n_flat, float max_grad_norm, double beta1, double beta2, double eps,
                          catppo_iter_state* state, void* stream);
 
+/* ABI 0.4: one optimiser step of a single process in ONE call = catppo_ppo_minibatch_grad_packed followed by
+ * catppo_clip_adam_dev (same arguments, same results up to the summation order of the fp64 squared norm), for callers
+ * with nothing to do between the two - no gradient all-reduce.  The workgroups that fold the split-K partials into the
+ * flat gradient also emit the sum of squares of what they write, so the clip needs no launch that re-reads the
+ * gradient: 6 launches per step instead of 7.
+ * replaces: cleanrl/ppo.py:298-356 (minibatch losses, backward, clip_grad_norm_, optimizer.step) of a non-distributed run. */
+int catppo_ppo_minibatch_step_packed(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_ppo_hparams* hp,
+                                     float* params, const float* x_mb, const float* act_mb, const float* scal_mb,
+                                     const double* adv_part_mb, int64_t M, const float* vrms_mean,
+                                     const float* vrms_var, const float* adv_stats, float* grad, float* diag,
+                                     float* exp_avg, float* exp_avg_sq, float max_grad_norm, double beta1, double beta2,
+                                     double eps, catppo_iter_state* state, void* stream);
+
 /* KL-adaptive learning rate, device side (no host sync).  Two calls so that an env-sharded run can put its
  * all-reduce between them:
  *   catppo_kl_mean        kl_out[0] = (diag[4] - kl_mark) / (diag[7] - n_mark): the mean approx-KL of the minibatches

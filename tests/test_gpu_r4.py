@@ -259,3 +259,30 @@ def test_in_launch_fold_tree_of_the_env_step_still_holds_the_fused_step_tests():
                        env=dict(os.environ, CATPPO_ROLLOUT_TREE="1"), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
     assert "2 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(),                                                                             # 3 x 256: dw_fold + final fold launch
+    dict(num_envs=1000, num_steps=4, minibatch=1000, epochs=1, iters=2, hidden=(512, 256, 128), obs_dim=235),
+    dict(num_envs=64, num_steps=8, minibatch=128, epochs=2, iters=2, six_terms=True),  # small minibatch (head_loss path)
+])
+def test_one_call_optimiser_step_equals_gradient_call_plus_clip_adam_call(kw):
+    """catppo_ppo_minibatch_step_packed (the fold launches emit the squared norm of the clip; 6 launches) against
+    catppo_ppo_minibatch_grad_packed + catppo_clip_adam_dev (7 launches) over whole iterations with the same noise and
+    permutations: the clipped gradient, both Adam moments and the parameters can differ only through the summation
+    order of the fp64 squared norm (<= 1 ulp of the fp32 clip coefficient), the step count not at all."""
+    import test_gpu_r2_features as R2
+    a, b = R2._two_trainers({"one_call_step": True}, {"one_call_step": False}, inject=True, **kw)
+    assert a.one_call_step and not b.one_call_step
+    sa, sb = a.nat.iter_state_read(a.state), b.nat.iter_state_read(b.state)
+    assert sa.adam_step == sb.adam_step > 0 and sa.adam_step_size == sb.adam_step_size
+    for name in ("grad", "exp_avg", "exp_avg_sq"):
+        x, y = getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy()
+        np.testing.assert_allclose(x, y, rtol=3e-7, atol=0, err_msg=name)
+    pa, pb = a.agent.flat.cpu().numpy(), b.agent.flat.cpu().numpy()
+    np.testing.assert_allclose(pa, pb, rtol=0, atol=2e-7)
+    assert np.abs(a.grad.cpu().numpy()).max() > 0 and np.isfinite(pa).all()
+    for name in ("values", "logprobs", "advantages"):
+        np.testing.assert_allclose(getattr(a, name).cpu().numpy(), getattr(b, name).cpu().numpy(), rtol=0, atol=2e-6,
+                                   err_msg=name)
+
