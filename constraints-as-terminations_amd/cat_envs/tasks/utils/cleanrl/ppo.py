@@ -19,7 +19,7 @@ runs in libcatppo.so (hand-written HIP, see include/catppo.h):
     epoch          catppo_ppo_gather_ex                       (keyed on-device permutation, no index array)
     minibatch      catppo_ppo_minibatch_grad_packed  [catppo_allreduce: RCCL SUM of the flat gradient]
                    catppo_clip_adam_dev                       (lr / step count from the device state)
-                   single process: both in one call, catppo_ppo_minibatch_step_packed (6 launches instead of 7)
+                   single process: both in one call, catppo_ppo_minibatch_step_packed (one launch fewer)
     [KL-adaptive]  catppo_kl_mean [catppo_allreduce] catppo_kl_adaptive_lr   after every epoch, no host sync
 The update phase is replayed from a hipGraph (``graph_update``; collectives of an env-sharded run included, with a
 reported eager fallback when the capture fails).

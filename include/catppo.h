@@ -394,7 +394,7 @@ int catppo_clip_adam_dev(catppo_ctx* ctx, float* params, float* grad, float* exp
  * catppo_clip_adam_dev (same arguments, same results up to the summation order of the fp64 squared norm), for callers
  * with nothing to do between the two - no gradient all-reduce.  The workgroups that fold the split-K partials into the
  * flat gradient also emit the sum of squares of what they write, so the clip needs no launch that re-reads the
- * gradient: 6 launches per step instead of 7.
+ * gradient: one launch fewer per step (7 instead of 8 at 16384 x 3 x 256).
  * replaces: cleanrl/ppo.py:298-356 (minibatch losses, backward, clip_grad_norm_, optimizer.step) of a non-distributed run. */
 int catppo_ppo_minibatch_step_packed(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_ppo_hparams* hp,
                                      float* params, const float* x_mb, const float* act_mb, const float* scal_mb,

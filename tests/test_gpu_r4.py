@@ -267,8 +267,8 @@ def test_in_launch_fold_tree_of_the_env_step_still_holds_the_fused_step_tests():
     dict(num_envs=64, num_steps=8, minibatch=128, epochs=2, iters=2, six_terms=True),  # small minibatch (head_loss path)
 ])
 def test_one_call_optimiser_step_equals_gradient_call_plus_clip_adam_call(kw):
-    """catppo_ppo_minibatch_step_packed (the fold launches emit the squared norm of the clip; 6 launches) against
-    catppo_ppo_minibatch_grad_packed + catppo_clip_adam_dev (7 launches) over whole iterations with the same noise and
+    """catppo_ppo_minibatch_step_packed (the fold launches emit the squared norm of the clip) against
+    catppo_ppo_minibatch_grad_packed + catppo_clip_adam_dev (one launch more) over whole iterations with the same noise and
     permutations: the clipped gradient, both Adam moments and the parameters can differ only through the summation
     order of the fp64 squared norm (<= 1 ulp of the fp32 clip coefficient), the step count not at all."""
     import test_gpu_r2_features as R2
