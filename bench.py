@@ -421,7 +421,8 @@ def main():
 
     if rank == 0:
         M = trainer.M
-        if trainer.graph_update:                   # eager replay of the group on the data of the last iteration
+        if trainer.graph_update or not ev:         # eager replay of the group on the data of the last iteration
+            # (also when the eager trainer took the one-call optimiser step, which the wrapper above does not see)
             trainer._update_buffers()
             # (env-sharded runs normalise advantages with the statistics of the GLOBAL minibatch: hand the kernel the
             # first pair the last iteration computed)
