@@ -338,6 +338,10 @@ def main():
             overrides[k] = v
     w = WORKLOADS[a.workload]
     shard_world = a.shard_of if (a.shard_of > 0 and world == 1) else world
+    if (shard_world > 1 and world == 1) or a.workload.endswith("_shard"):
+        # one rank's share of an env-sharded job run as a single process: a real rank has its gradient all-reduce between
+        # the fold and the clip, so it takes the two-call optimiser step - and so does its stand-in
+        overrides.setdefault("one_call_step", False)
     # stdout carries ONE line (the JSON record): what building the env prints (the reference's "[INFO] Constraint
     # Manager" table) goes to stderr
     import contextlib
@@ -477,6 +481,7 @@ def main():
                                        if world > 1 else "none"),
                        "self_launched": os.environ.get("CATPPO_BENCH_SELF_LAUNCHED") == "1",
                        "grad_overlap": trainer.grad_overlap, "graph_fallback": trainer.graph_fallback,
+                       "one_call_optimiser_step": trainer.one_call_step,
                        "timed_region": "K x run_iteration(log=True): includes the per-iteration diagnostics read-back",
                        "simulated_shard_of_world": a.shard_of if a.shard_of > 0 else None,
                        "rng": trainer.rng, "fused_rollout": trainer.sink is not None,
