@@ -431,11 +431,18 @@ def main():
             # (env-sharded runs normalise advantages with the statistics of the GLOBAL minibatch: hand the kernel the
             # first pair the last iteration computed)
             adv_stats = trainer._adv_stats_all[0] if trainer.hp.adv_stats_external else None
+            # rank 0 is alone here: with gradient buckets on, the gradient call itself would all-reduce - and wait for
+            # peers that are already at the final barrier
+            ov_replay = bool(trainer.grad_overlap)
+            if ov_replay:
+                nat.set_grad_overlap(False)
             for _ in range(12):
                 timed_grad(trainer.agent.shape, trainer.hp, trainer.agent.flat, trainer._x_g, trainer._act_g,
                            trainer._scal_g, trainer._advp_g, M, trainer.agent.value_rms.running_mean,
                            trainer.agent.value_rms.running_var, adv_stats, trainer.grad, trainer.diag)
             torch.cuda.synchronize()
+            if ov_replay:
+                nat.set_grad_overlap(True)
             ev[:] = ev[2:]
         grad_us = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
         macs = fwd_macs(w["obs_dim"], w["hidden"])
