@@ -30,6 +30,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL / device-tensor sharing fail with
+# "hipIpcGetMemHandle: invalid argument" otherwise): in the environment BEFORE the HIP runtime comes up in this process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 

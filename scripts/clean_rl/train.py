@@ -89,6 +89,8 @@ def _main(args_cli):
         from cat_envs.shim import hydra_task_config
 
     if torch.distributed.is_available() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # dmabuf IPC for RCCL on this platform; must be in the environment before the first HIP call of the process
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
