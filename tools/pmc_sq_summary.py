@@ -12,7 +12,7 @@ import json
 import sys
 
 SIMDS_PER_INSTANCE = 32
-KEEP = ("gemm", "dw_fold", "rows_fwd", "fused_fwd", "head_loss", "fwd_head", "head_act", "seg_reduce", "cat_", "rms_", "gae_scan", "clip_adam", "sqnorm", "ppo_gather", "rollout_pre", "rollout_post",
+KEEP = ("gemm", "dw_fold", "rows_fwd", "fused_fwd", "head_loss", "fwd_head", "head_act", "seg_reduce", "cat_", "rms_", "gae_scan", "clip_adam", "sqnorm", "ppo_gather", "rollout_pre", "rollout_fold", "rollout_post",
         "env_pre_step", "rollout_store")
 
 
