@@ -380,8 +380,10 @@ def main():
     trainer.time_phases = True
     barrier()
     t0 = time.perf_counter()
+    # (CATPPO_BENCH_TIMED_LOG=0: A/B of what the read-back costs - never the reported configuration)
+    timed_log = os.environ.get("CATPPO_BENCH_TIMED_LOG", "1") != "0"
     for _ in range(a.steps):
-        trainer.run_iteration(log=True)           # log=True: the per-iteration diagnostics read-back is inside the metric
+        trainer.run_iteration(log=timed_log)      # log=True: the per-iteration diagnostics read-back is inside the metric
     barrier()
     dt = time.perf_counter() - t0
     nat.ppo_minibatch_grad_packed = orig
@@ -492,7 +494,7 @@ def main():
                                        if world > 1 else "none"),
                        "self_launched": os.environ.get("CATPPO_BENCH_SELF_LAUNCHED") == "1",
                        "grad_overlap": trainer.grad_overlap, "graph_fallback": trainer.graph_fallback,
-                       "one_call_optimiser_step": trainer.one_call_step,
+                       "one_call_optimiser_step": trainer.one_call_step, "readback_in_timed_region": timed_log,
                        "timed_region": "K x run_iteration(log=True): includes the per-iteration diagnostics read-back",
                        "simulated_shard_of_world": a.shard_of if a.shard_of > 0 else None,
                        "rng": trainer.rng, "fused_rollout": trainer.sink is not None,
