@@ -32,7 +32,10 @@ import time
 
 # multi-process GPU work on this platform needs dmabuf IPC (RCCL / device-tensor sharing fail with
 # "hipIpcGetMemHandle: invalid argument" otherwise): in the environment BEFORE the HIP runtime comes up in this process
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+if os.environ.get("CATPPO_BENCH_IPC_UNSET") != "1":
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+        os.environ["CATPPO_BENCH_IPC_DEFAULTED"] = "1"        # (self_launch: the value is ours, not the user's)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -258,13 +261,31 @@ def self_launch(n_ranks: int) -> int:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this host driver
+    # dmabuf IPC: this image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (the host driver only supports dmabuf IPC; RCCL /
+    # device-tensor sharing otherwise fail with "hipIpcGetMemHandle: invalid argument").  No run with more than one
+    # RCCL rank has been possible on the one-GPU development boxes, so the value is a documented platform requirement,
+    # not something measured here: a user's explicit setting always wins, and if the ranks fail with the default the
+    # launch is retried ONCE with the variable removed - the line says which attempt produced it (config.comm_env).
+    user_set = "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ and os.environ.get("CATPPO_BENCH_IPC_DEFAULTED") != "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     env["CATPPO_BENCH_SELF_LAUNCHED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
     print(f"[bench] --gpus {n_ranks} without a launcher: starting {n_ranks} ranks: {' '.join(cmd)}", file=sys.stderr)
-    return subprocess.call(cmd, env=env)
+    env["CATPPO_BENCH_LAUNCH_ATTEMPT"] = "1"
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0 and not user_set and os.environ.get("CATPPO_BENCH_NO_RETRY") != "1":
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd[cmd.index("--master-port") + 1] = str(port)
+        env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+        env["CATPPO_BENCH_LAUNCH_ATTEMPT"] = "2"
+        env["CATPPO_BENCH_IPC_UNSET"] = "1"
+        print(f"[bench] the ranks exited with code {rc}; retrying once WITHOUT HSA_ENABLE_IPC_MODE_LEGACY", file=sys.stderr)
+        rc = subprocess.call(cmd, env=env)
+    return rc
 
 
 def main():
@@ -272,7 +293,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None,
+                    help="default cfg2 (BASELINE configs[1]); with --scaling strong: cfg3")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="weak (default): every rank owns the workload's envs and minibatch.  strong = --workload cfg3: "
+                         "BASELINE configs[2] as written, 16384 envs and a 16384-row minibatch GLOBAL, sharded over the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mlp-precision", choices=("fp32", "bf16", "bf16x3"), default=None,
                     help="fp32 = fp32-input MFMA (the headline metric).  bf16x3 = split-bf16 operands (3 bf16 MFMAs per "
@@ -290,6 +315,10 @@ def main():
     a = ap.parse_args()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if a.workload is None:
+        a.workload = "cfg3" if a.scaling == "strong" else "cfg2"
+    if a.scaling is not None and (a.scaling == "strong") != bool(WORKLOADS[a.workload].get("strong")):
+        ap.error(f"--scaling {a.scaling} contradicts --workload {a.workload} (strong scaling is --workload cfg3)")
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         if a.print_launch:
@@ -318,17 +347,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(dev_index)
         if shared:
-            # RCCL refuses two ranks on one device: gloo process group, device operands staged through host memory by
-            # cat_envs.parallel (the transport of tests/test_gpu_two_rank_trainer.py) - correct, slow, never production
+            # RCCL refuses two ranks on one device: device operands staged through host memory by cat_envs.parallel (the
+            # transport of tests/test_gpu_two_rank_trainer.py) - correct, slow, never production
             os.environ["CATPPO_NATIVE_COMM"] = "0"
-            torch.distributed.init_process_group("gloo")
-        else:
-            # torch.distributed is the rendezvous (unique-id exchange, barrier); the data-path collectives are
-            # catppo_allreduce on libcatppo's own RCCL communicator
-            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", dev_index))   # nccl == RCCL on ROCm
+            os.environ["CATPPO_RANKS_SHARE_GPU"] = "1"
+        # The rendezvous (unique-id exchange, votes, barriers) is a gloo (CPU) process group: the ONLY RCCL communicator
+        # of this process is libcatppo's own (catppo_comm_init), which carries every data-path collective.  (Round 4
+        # initialised torch's "nccl" group here just to ship 128 bytes: a second RCCL bootstrap on the first real run.)
+        from cat_envs import parallel as _par
+        _par.init_rendezvous(dev_index)
     else:
         torch.cuda.set_device(0)
 
@@ -389,10 +418,15 @@ def main():
     nat.ppo_minibatch_grad_packed = orig
     phases = trainer.phase_summary()
     trainer.time_phases = False
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        parallel.allreduce_max_(t)        # RCCL, or host-staged gloo when the ranks share a device
-        dt = float(t)
+        # MAX over ranks is the job's time; min / max / every rank's own time make stragglers visible (CPU gather over
+        # the rendezvous group: not on the data path)
+        times = [None] * world
+        torch.distributed.all_gather_object(times, dt)
+        per_rank_ms = {"min": 1e3 * min(times) / a.steps, "max": 1e3 * max(times) / a.steps,
+                       "by_rank": [1e3 * x / a.steps for x in times]}
+        dt = max(times)
     env_total = trainer.n_envs_global if world > 1 else float(trainer.N)
     steps_total = env_total * w["num_steps"] * a.steps
     value = steps_total / dt
@@ -492,6 +526,12 @@ def main():
                                        "torch.distributed" + (f" (native set-up failed: {parallel.native_comm_error()})"
                                                               if parallel.native_comm_error() else "")
                                        if world > 1 else "none"),
+                       "native_comm_error": parallel.native_comm_error(),
+                       "comm_env": dict(parallel.comm_env(), launch_attempt=int(os.environ.get("CATPPO_BENCH_LAUNCH_ATTEMPT", "0")),
+                                        ipc_mode_set_by=("retry: unset" if os.environ.get("CATPPO_BENCH_IPC_UNSET") == "1" else
+                                                         "bench.py default" if os.environ.get("CATPPO_BENCH_IPC_DEFAULTED") == "1"
+                                                         else "environment")),
+                       "scaling_mode": "strong" if w.get("strong") else "weak",
                        "self_launched": os.environ.get("CATPPO_BENCH_SELF_LAUNCHED") == "1",
                        "grad_overlap": trainer.grad_overlap, "graph_fallback": trainer.graph_fallback,
                        "one_call_optimiser_step": trainer.one_call_step, "readback_in_timed_region": timed_log,
@@ -500,6 +540,7 @@ def main():
                        "rng": trainer.rng, "fused_rollout": trainer.sink is not None,
                        "graph_update": trainer.graph_update, "graph_nodes": trainer.graph_nodes,
                        "overrides": overrides},
+            "per_rank_ms": per_rank_ms,
             "ms_per_step_no_readback": 1e3 * dt_nolog / a.steps,
             "comm_ms_per_iteration": None if comm is None else comm["ms"] / comm["iterations"],
             "comm": None if comm is None else {

@@ -190,6 +190,8 @@ _SIGNATURES = {
     "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "catppo_rlg_episode_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    # ---- ABI 0.5
+    "catppo_adv_moments_keyed": (C.c_int, [_vp, _vp, C.c_int, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     # ---- ABI 0.4
     "catppo_set_grad_overlap": (C.c_int, [_vp, C.c_int]),
     "catppo_grad_overlap_active": (C.c_int, [_vp]),
@@ -409,6 +411,15 @@ class Native:
         _chk(moments, torch.float64, "moments")
         self._ok(self.lib.catppo_adv_moments_parts(self.h, _p(adv_part_g), int(parts_per_mb), int(total),
                                                    int(minibatch), _p(moments), self._stream()))
+
+    def adv_moments_keyed(self, advantages, st, n_epochs, total, minibatch, parts_scratch, moments):
+        """{sum, sum of squares, rows} of every minibatch of ALL ``n_epochs`` keyed permutations of this iteration
+        (ABI 0.5): moments (n_epochs * n_mb, 3) fp64; parts_scratch: n_epochs * n_mb * ceil(minibatch / 64) * 2 fp64"""
+        _chk(moments, torch.float64, "moments")
+        _chk(parts_scratch, torch.float64, "parts_scratch")
+        self._ok(self.lib.catppo_adv_moments_keyed(self.h, _p(advantages), self._dt(advantages), _p(st), int(n_epochs),
+                                                   int(total), int(minibatch), _p(parts_scratch), _p(moments),
+                                                   self._stream()))
 
     def adv_stats(self, moments, n_minibatches, stats):
         self._ok(self.lib.catppo_adv_stats(self.h, _p(moments), int(n_minibatches), _p(stats), self._stream()))

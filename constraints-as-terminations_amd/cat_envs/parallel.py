@@ -11,6 +11,12 @@ The last three make N ranks reproduce ONE process on the union of the shards (SU
 helpers are device agnostic: on the GPUs they call RCCL directly through libcatppo's C ABI (catppo_comm_init /
 catppo_allreduce, see init_native_comm) - torch.distributed is only the rendezvous that ships the 128-byte unique id -
 and on CPU tensors (the gloo tests) they fall back to torch.distributed.
+
+Round 5: the rendezvous is a GLOO (CPU) process group (``init_rendezvous``), so a rank creates exactly ONE RCCL
+communicator - libcatppo's - instead of torch's "nccl" group (a whole second RCCL bootstrap with its own channel
+buffers, created only to ship 128 bytes and a few votes) plus ours.  If the native communicator cannot be set up the
+ranks agree on that (votes over gloo) and only THEN create a torch "nccl" group for the device operands
+(``_device_fallback_group``); ranks that share one GPU (launcher proof on a one-GPU box) stage through host memory.
 """
 from __future__ import annotations
 
@@ -25,6 +31,43 @@ _native = None
 
 
 _native_error = None
+#: torch "nccl" group created lazily for device operands when the rendezvous group is gloo and libcatppo's own
+#: communicator is unavailable (None: not needed / ranks share a device: host staging)
+_device_fallback_group = None
+#: what the communicator set-up saw of the environment (bench.py prints it as ``config.comm_env``)
+_comm_env = {}
+
+
+def init_rendezvous(local_device: int | None = None, timeout_s: float = 600.0):
+    """Process group of the launcher's ranks for everything that is NOT the data path: the unique id of libcatppo's RCCL
+    communicator, the set-up votes, barriers, Python-object gathers.  Backend gloo (CPU, TCP on MASTER_ADDR): no RCCL
+    communicator is created by torch.  Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT like torch.distributed.run
+    sets them (reference precedent: scripts/skrl/train.py:116-117 initialises its process group from the same
+    variables).  ``local_device`` selects the HIP device of this rank first."""
+    import datetime
+    if local_device is not None and torch.cuda.is_available():
+        torch.cuda.set_device(local_device)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    return dist.group.WORLD
+
+
+def comm_env() -> dict:
+    """environment facts of the communicator set-up (for the bench line): the dmabuf IPC switch RCCL needs on this
+    platform, who set it, the rendezvous backend, and which transport carries device operands"""
+    d = dict(_comm_env)
+    d["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")
+    d["rendezvous_backend"] = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+    d["device_transport"] = ("libcatppo RCCL communicator" if _native is not None else
+                             "torch nccl group (fallback)" if _device_fallback_group is not None else
+                             "host staging over gloo" if d["rendezvous_backend"] == "gloo" else
+                             "torch.distributed" if d["rendezvous_backend"] else "none")
+    return d
+
+
+def _ranks_share_device() -> bool:
+    return os.environ.get("CATPPO_RANKS_SHARE_GPU", "0") == "1"
 
 
 def init_native_comm(nat, group=None) -> bool:
@@ -36,7 +79,10 @@ def init_native_comm(nat, group=None) -> bool:
     global _native
     if _native is not None:
         return True
-    if not active(group) or os.environ.get("CATPPO_NATIVE_COMM", "1") == "0":
+    if not active(group):
+        return False
+    if os.environ.get("CATPPO_NATIVE_COMM", "1") == "0":
+        _ensure_device_fallback(group)      # the switch is an environment variable of the job: every rank sees it
         return False
     # Every rank must end up on the same transport, and nobody may enter the (blocking) communicator set-up unless
     # everybody can: ncclCommInitRank waits for all ranks, so a rank that failed BEFORE it (librccl not loadable, a
@@ -84,9 +130,38 @@ def init_native_comm(nat, group=None) -> bool:
             import sys
             print(f"[catppo] native RCCL communicator unavailable, collectives stay on torch.distributed: "
                   f"{_native_error}", file=sys.stderr)
+        _ensure_device_fallback(group)
         return False
     _native = nat
     return True
+
+
+def _ensure_device_fallback(group=None):
+    """Rendezvous on gloo and no native communicator: device operands need a device transport after all.  Every rank
+    reaches this point together (it follows a collective vote), so the collective ``new_group`` is safe.  Ranks that
+    share a GPU keep the host-staged path (RCCL refuses two ranks on one device)."""
+    global _device_fallback_group
+    if _device_fallback_group is not None or not dist.is_initialized() or world_size(group) < 2:
+        return
+    if dist.get_backend(group) != "gloo" or not torch.cuda.is_available():
+        return
+    # two ranks on one device (a one-GPU box: the 2-rank trainer tests, bench.py's launcher proof) cannot form an RCCL
+    # group: every rank publishes which physical device it sits on, and any duplicate keeps ALL ranks on host staging
+    import socket
+    dev = torch.cuda.current_device()
+    ident = (socket.gethostname(), os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES", "")),
+             str(getattr(torch.cuda.get_device_properties(dev), "uuid", dev)), dev)
+    idents = [None] * world_size(group)
+    dist.all_gather_object(idents, ident, group=group)
+    _comm_env["ranks_share_a_device"] = len(set(idents)) < len(idents)
+    if _ranks_share_device() or _comm_env["ranks_share_a_device"]:
+        return
+    try:
+        _device_fallback_group = dist.new_group(backend="nccl")
+    except Exception as e:                                      # stay on host staging: slow, correct
+        import sys
+        print(f"[catppo] rank {rank(group)}: torch nccl fallback group unavailable ({e}); device operands are staged "
+              f"through host memory", file=sys.stderr)
 
 
 #: seconds the known-answer pass may take before the communicator is declared unusable (first RCCL call: lazy channel set-up)
@@ -121,13 +196,13 @@ def _selfcheck(nat, r: int, w: int):
                 time.sleep(0.002)
         ranks = torch.arange(w, device=dev, dtype=torch.float64)
         exp32 = (w * ((i % 7) + 1) + ranks.sum()).float()
-        exp64 = (i + 1) * (ranks + 1).sum()
+        exp64 = (i + 1) * (ranks + 1).sum() + 1e-9 * ranks.sum()      # the per-rank perturbation is part of the answer
         exp16 = float(sum(k % 3 for k in range(w)))
         expm = torch.stack([(i * 31 + 17 * k) % 101 for k in range(w)]).max(0).values.float()
         bad = []
         if not torch.equal(s32, exp32):
             bad.append("SUM fp32")
-        if not torch.allclose(s64, exp64, rtol=1e-12, atol=1e-8 * w):
+        if not torch.allclose(s64, exp64, rtol=1e-12, atol=1e-10):
             bad.append("SUM fp64")
         if not bool((s16.float() == exp16).all()):
             bad.append("SUM fp16")
@@ -148,10 +223,24 @@ def native_comm_error():
 
 
 def shutdown_native_comm():
-    global _native
+    global _native, _device_fallback_group
     if _native is not None:
         _native.comm_destroy()
         _native = None
+    _device_fallback_group = None          # destroyed with the process group
+
+
+def reinit_native_comm(group=None) -> bool:
+    """Destroy libcatppo's communicator and build a fresh one (collective: every rank must call it).  Used after a
+    stream capture that enqueued collectives was aborted on some rank: that rank's communicator state may be ahead of
+    its peers' (ADVICE r4), so nobody keeps using the old one."""
+    global _native
+    nat = _native
+    if nat is None:
+        return False
+    nat.comm_destroy()
+    _native = None
+    return init_native_comm(nat, group)
 
 
 def native_comm_active() -> bool:
@@ -190,7 +279,15 @@ def _host_staged(t: torch.Tensor, group) -> bool:
     """device tensor on a process group whose backend has no device transport here (gloo: the CPU tests' backend,
     and the way two ranks share ONE GPU in the 2-rank trainer test - RCCL refuses two ranks on one device): the
     operand takes a round trip through host memory.  Correct, deterministic and slow; never the production transport."""
-    return t.is_cuda and dist.get_backend(group) == "gloo"
+    return t.is_cuda and dist.get_backend(group) == "gloo" and _device_fallback_group is None
+
+
+def _torch_group(t: torch.Tensor, group):
+    """the torch.distributed group that carries ``t``: the nccl fallback group for device operands of the (gloo) world
+    group when it exists, else the caller's group"""
+    if t.is_cuda and _device_fallback_group is not None and group in (None, dist.group.WORLD):
+        return _device_fallback_group
+    return group
 
 
 #: [(kind, bytes, start event, end event)] while comm_timing_begin() ... comm_timing_end() brackets a region (bench.py's
@@ -226,7 +323,9 @@ class _timed:
     """brackets one exchange point with HIP events when comm timing is on (device operands only)"""
 
     def __init__(self, kind, t):
-        self.on = _timing is not None and t.is_cuda
+        # (an event recorded inside a stream capture belongs to the graph: it cannot be timed - the captured update phase
+        # is measured by bench.py's un-graphed pass instead)
+        self.on = _timing is not None and t.is_cuda and not torch.cuda.is_current_stream_capturing()
         self.kind, self.nbytes = kind, t.numel() * t.element_size()
 
     def __enter__(self):
@@ -259,17 +358,17 @@ def _collective(t: torch.Tensor, group, native_call, torch_call, kind="allreduce
 
 def allreduce_sum_(t: torch.Tensor, group=None) -> torch.Tensor:
     return _collective(t, group, lambda x: _native.allreduce(x, 0),
-                       lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group))
+                       lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=_torch_group(x, group)))
 
 
 def allreduce_max_(t: torch.Tensor, group=None) -> torch.Tensor:
     return _collective(t, group, lambda x: _native.allreduce(x, 1),
-                       lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=group))
+                       lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX, group=_torch_group(x, group)))
 
 
 def broadcast_(t: torch.Tensor, src: int = 0, group=None) -> torch.Tensor:
     return _collective(t, group, lambda x: _native.broadcast(x, src),
-                       lambda x: dist.broadcast(x, src=src, group=group), kind="broadcast")
+                       lambda x: dist.broadcast(x, src=src, group=_torch_group(x, group)), kind="broadcast")
 
 
 def allgather_bytes_(send: torch.Tensor, recv: torch.Tensor, group=None) -> torch.Tensor:
@@ -287,7 +386,7 @@ def allgather_bytes_(send: torch.Tensor, recv: torch.Tensor, group=None) -> torc
             dist.all_gather_into_tensor(h, send.detach().cpu(), group=group)
             recv.copy_(h)
         else:
-            dist.all_gather_into_tensor(recv, send, group=group)
+            dist.all_gather_into_tensor(recv, send, group=_torch_group(send, group))
     return recv
 
 

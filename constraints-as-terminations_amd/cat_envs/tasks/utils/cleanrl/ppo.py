@@ -96,6 +96,37 @@ class RunningMeanStd(nn.Module):
         else:
             nat.rms_update_ex(rows, n, d, rows.stride(0), self.running_mean, self.running_var, self.count)
 
+    def update_normalize_pair(self, rows_a, out_a, rows_b, out_b):
+        """``normalize_into(rows_a, out_a)`` followed by ``normalize_into(rows_b, out_b)`` (the value normaliser's two
+        updates per iteration, reference ppo.py:287-288) with ONE exchange between ranks: the batch moments of the two
+        batches do not depend on each other - only the two Chan merges are sequential - so an env-sharded run sums
+        both moment pairs in a single all-reduce (round 5; one collective per iteration instead of two).  Same
+        arithmetic, same order, as the two separate calls."""
+        group = self.dist_group
+        if group is None or not parallel.active(group) or os.environ.get("CATPPO_VRMS_PAIR", "1") == "0":   # (A/B switch)
+            self.normalize_into(rows_a, out_a)
+            self.normalize_into(rows_b, out_b)
+            return
+        nat = native.get(rows_a.device)
+        (na, d), (nb, db) = rows_a.shape, rows_b.shape
+        assert d == db == self.dim
+        if not hasattr(self, "_sums_pair"):
+            self._sums_pair = torch.zeros(4 * d, dtype=torch.float64, device=rows_a.device)
+            self._n_global = getattr(self, "_n_global", {})
+        sa, sb = self._sums_pair[:2 * d], self._sums_pair[2 * d:]
+        nat.rms_moments_ex(rows_a, na, d, rows_a.stride(0), sa)
+        nat.rms_moments_ex(rows_b, nb, d, rows_b.stride(0), sb)
+        parallel.global_moment_sums(self._sums_pair, group)
+        for n in (na, nb):
+            if n not in self._n_global:
+                cnt = torch.tensor([float(n)], dtype=torch.float64, device=rows_a.device)
+                parallel.allreduce_sum_(cnt, group)
+                self._n_global[n] = float(cnt.item())
+        nat.rms_merge(sa, self._n_global[na], d, self.running_mean, self.running_var, self.count)
+        self.normalize_into(rows_a, out_a, update=False)
+        nat.rms_merge(sb, self._n_global[nb], d, self.running_mean, self.running_var, self.count)
+        self.normalize_into(rows_b, out_b, update=False)
+
     def update_from_moments(self, batch_mean, batch_var, batch_count):
         """Chan merge of externally computed batch moments (reference ppo.py:33-45).  Not on the training path -
         ``update()`` fuses the moment pass and this merge on the device - so plain tensor ops, in place."""
@@ -425,11 +456,17 @@ class PPOTrainer:
             # gaps the graph removes); round 2 only enabled it up to 4096 rows
             g = True
         dist_on_torch = parallel.active() and not parallel.native_comm_active()
-        # RCCL collectives sit inside the captured graph by default at every world size (round 4; they are stream
-        # operations under the C ABI).  If the capture or the first replay fails on some node the update phase falls
-        # back to eager launches and says so (``graph_fallback``, stderr, bench.py's JSON line) instead of failing the
-        # run; CATPPO_GRAPH_COMM=0 keeps collectives out of graphs altogether.
-        dist_in_graph_ok = self.world == 1 or os.environ.get("CATPPO_GRAPH_COMM", "1") != "0"
+        # RCCL collectives inside the captured graph (they are stream operations under the C ABI): exercised on a world of
+        # one (tests) - but no run with real peers has been possible on the one-GPU development boxes, a hang or an
+        # asynchronous fault inside a REPLAYED graph cannot be caught and turned into the eager fallback, and the update
+        # phase of an env-sharded run is GPU bound (graph replay buys ~1 % at 16384-row minibatches).  So with real peers
+        # it is OPT-IN again (round 5): CATPPO_GRAPH_COMM=1 / cfg ``graph_comm=True`` once a node has shown it
+        # works.  When on: the ranks agree (a vote over the rendezvous group) on whether EVERY rank captured and replayed;
+        # otherwise all of them drop to eager launches together on a fresh communicator (``graph_fallback``).
+        gc = getattr(c, "graph_comm", None)
+        if os.environ.get("CATPPO_GRAPH_COMM") is not None:
+            gc = os.environ["CATPPO_GRAPH_COMM"] != "0"
+        dist_in_graph_ok = self.world == 1 or bool(gc)
         self.graph_update = bool(g) and self.rng == "device" and not dist_on_torch and dist_in_graph_ok
         #: why the update phase left the graph path (None: it did not)
         self.graph_fallback = None
@@ -564,9 +601,10 @@ class PPOTrainer:
             nat.gae_mode(native.GAE_SCAN, *args)
         else:
             nat.gae(*args)
-        # value_rms is updated with the values and then, a second time, with the returns (:287-288)
-        a.value_rms.normalize_into(self.values.view(-1, 1), self.values_n.view(-1, 1))
-        a.value_rms.normalize_into(self.returns.view(-1, 1), self.returns_n.view(-1, 1))
+        # value_rms is updated with the values and then, a second time, with the returns (:287-288); env-sharded runs
+        # exchange both batches' moments in one all-reduce
+        a.value_rms.update_normalize_pair(self.values.view(-1, 1), self.values_n.view(-1, 1),
+                                          self.returns.view(-1, 1), self.returns_n.view(-1, 1))
 
     # ------------------------------------------------------------------ update (:294-354)
     def _update_buffers(self):
@@ -579,6 +617,7 @@ class PPOTrainer:
             self._scal_g = torch.empty(4 * B, device=self.device)
             self._advp_g = torch.empty(n_mb * self._parts * 2, dtype=torch.float64, device=self.device)
             E = int(self.cfg.updates_epochs)
+            self._advp_all = torch.empty(E * n_mb * self._parts * 2, dtype=torch.float64, device=self.device)
             self._adv_mom = torch.zeros(E * n_mb, 3, dtype=torch.float64, device=self.device)
             self._adv_stats_all = torch.zeros(E * n_mb, 2, device=self.device)
 
@@ -596,12 +635,20 @@ class PPOTrainer:
         E = int(c.updates_epochs)
         exact_adv = parallel.active() and bool(c.norm_adv) and getattr(c, "dist_exact", True)
         self.hp.adv_stats_external = int(exact_adv)
+        # keyed on-device permutations: the minibatch advantage moments of ALL epochs are a function of (seed, iteration,
+        # epoch) and the advantages alone, so they are formed before the first gather and exchanged in ONE all-reduce per
+        # iteration (round 5; one per epoch before).  Injected / torch permutations keep the per-epoch route.
+        adv_upfront = exact_adv and perms is None and os.environ.get("CATPPO_ADV_UPFRONT", "1") != "0"
+        if adv_upfront:
+            nat.adv_moments_keyed(b_adv, self.state, E, B, M, self._advp_all, self._adv_mom)
+            parallel.allreduce_sum_(self._adv_mom)
+            nat.adv_stats(self._adv_mom, E * n_mb, self._adv_stats_all)
         for epoch in range(E):
             rec = self.perm_rec[epoch] if self.perm_rec is not None else None
             nat.ppo_gather_ex(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, B, M, self._x_g, self._act_g,
                               self._scal_g, self._advp_g, inds=None if perms is None else perms[epoch],
                               st=self.state, epoch=epoch, inds_out=rec if perms is None else None)
-            if exact_adv:
+            if exact_adv and not adv_upfront:
                 # minibatch advantage mean / unbiased std over ALL ranks (ppo.py:316-318): the moments of every
                 # minibatch of the epoch from the chunk sums the gather just wrote (any plane precision, no index
                 # array), ONE all-reduce, one finishing launch
@@ -669,17 +716,48 @@ class PPOTrainer:
                     self.nat.graph_abort()
                     raise
                 gid, self.graph_nodes = self.nat.graph_end()
-                # nothing has executed so far (a capture records, it does not run): a failing first replay leaves the
-                # update phase undone as well, so the eager path below is the whole phase, not a repeat
-                self.nat.graph_launch(gid)
             except RuntimeError as e:
+                gid, err = None, e
+            else:
+                err = None
+            if parallel.active() and self.world > 1:
+                # every rank learns whether EVERY rank holds a graph before anybody replays: a rank whose capture failed
+                # after enqueueing collectives may have left its communicator ahead of its peers'  - then
+                # nobody replays, and all ranks continue eagerly on a FRESH communicator
+                votes = [None] * self.world
+                torch.distributed.all_gather_object(votes, None if err is None else f"{type(err).__name__}: {err}")
+                bad = [(i, v) for i, v in enumerate(votes) if v is not None]
+                if bad:
+                    if gid is not None:
+                        self.nat.graph_destroy(gid)
+                    gid = None
+                    err = err or RuntimeError("capture failed on " + "; ".join(f"rank {i}: {v}" for i, v in bad))
+                    parallel.reinit_native_comm()
+            if err is None:
+                # nothing has executed so far (a capture records, it does not run)
+                steps_before = int(self.nat.iter_state_read(self.state).adam_step) if parallel.active() else None
+                try:
+                    self.nat.graph_launch(gid)
+                except RuntimeError as e:
+                    err = e
+                    # a failing launch normally leaves the phase undone - but a deferred asynchronous error, or a
+                    # partially enqueued graph, would make the eager re-run below apply optimiser steps twice on this
+                    # rank only.  The device-side Adam step count says which: re-run only if it has not moved.
+                    if parallel.active():
+                        torch.cuda.synchronize()
+                        moved = int(self.nat.iter_state_read(self.state).adam_step) - steps_before
+                        self.nat.graph_destroy(gid)
+                        if moved != 0:
+                            raise RuntimeError(f"hipGraph replay of the update phase failed after {moved} optimiser steps "
+                                               f"had executed ({e}); refusing to re-run the phase eagerly") from e
+            if err is not None:
                 self._graph_id = None
                 if not parallel.active():
-                    raise                                        # single process: the error surfaces as before
+                    raise err                                    # single process: the error surfaces as before
                 # env-sharded run: collectives inside a graph are the one thing a one-GPU box cannot prove.  Fall back
-                # to eager launches (same launches, same order, same collectives: peers that did capture stay in step)
+                # to eager launches (same launches, same order, same collectives)
                 self.graph_update = False
-                self.graph_fallback = f"{type(e).__name__}: {e}"
+                self.graph_fallback = f"{type(err).__name__}: {err}"
                 import sys
                 print(f"[catppo] rank {self.rank}: hipGraph capture / first replay of the update phase failed, "
                       f"falling back to eager launches: {self.graph_fallback}", file=sys.stderr)

@@ -6,6 +6,7 @@
 //   rollout_store  : rewards[step] / dones[step+1] / true_dones[step+1] of the PPO rollout buffer
 //                    (reference cleanrl/ppo.py:215-216,226)            - replaces 3 tiny torch launches
 #include "common.h"
+#include "rng.h"
 
 namespace {
 
@@ -146,6 +147,52 @@ __global__ __launch_bounds__(64) void adv_moments_parts_kernel(const double* __r
   }
 }
 
+// Round 5: the chunk sums of EVERY epoch of an iteration without the gather (grid = chunks x minibatches x epochs): the
+// keyed permutation of epoch e is a function of (seed, iteration, e) alone (rng.h), so the advantage moments of all
+// E x n_mb minibatches can be formed - and exchanged between ranks in ONE all-reduce - before the first epoch starts.
+// Per 64-row chunk the statement sequence is ppo_gather_kernel's (widen, square in fp64, wave butterfly): the chunk
+// sums, and with them the statistics, are bit-identical to the per-epoch route through the gather's own partials.
+template <typename AT>
+__global__ __launch_bounds__(64) void adv_parts_keyed_kernel(const AT* __restrict__ adv,
+                                                             const catppo_iter_state* __restrict__ st, int64_t total,
+                                                             int64_t M, int parts_per_mb, double* __restrict__ parts) {
+  const int mbk = blockIdx.y, epoch = blockIdx.z;
+  const int64_t m0 = (int64_t)mbk * M;
+  const int64_t Mm = (total - m0) < M ? (total - m0) : M;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  double a1 = 0.0, a2 = 0.0;
+  if (r0 + threadIdx.x < Mm) {
+    rng::FeistelPerm perm;
+    perm.init(st->seed, st->iteration, epoch, total);
+    const int64_t src = perm(m0 + r0 + threadIdx.x);
+    a1 = (double)(float)adv[src];
+    a2 = a1 * a1;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a1 += __shfl_xor(a1, m, 64), a2 += __shfl_xor(a2, m, 64);
+  if (threadIdx.x == 0) {
+    double* p = parts + 2 * (((int64_t)epoch * gridDim.y + mbk) * parts_per_mb + blockIdx.x);
+    p[0] = a1, p[1] = a2;
+  }
+}
+
+// parts [E * n_mb][parts_per_mb][2] -> moments [E * n_mb][3]: adv_moments_parts_kernel with the epoch folded into the grid
+__global__ __launch_bounds__(64) void adv_moments_parts_epochs_kernel(const double* __restrict__ parts, int parts_per_mb,
+                                                                      int n_mb, int64_t total, int64_t mb,
+                                                                      double* __restrict__ out) {
+  const double* p = parts + 2 * (int64_t)blockIdx.x * parts_per_mb;
+  double a = 0.0, b = 0.0;
+  for (int c = threadIdx.x; c < parts_per_mb; c += 64) a += p[2 * c], b += p[2 * c + 1];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) a += __shfl_xor(a, m, 64), b += __shfl_xor(b, m, 64);
+  if (threadIdx.x == 0) {
+    const int64_t lo = (int64_t)(blockIdx.x % n_mb) * mb, hi = lo + mb < total ? lo + mb : total;
+    out[3 * blockIdx.x] = a;
+    out[3 * blockIdx.x + 1] = b;
+    out[3 * blockIdx.x + 2] = (double)(hi - lo);
+  }
+}
+
 // moments (after the SUM all-reduce) -> {mean, unbiased std + 1e-8} per minibatch (ppo.py:316-318)
 __global__ void adv_stats_kernel(const double* __restrict__ mom, int n, float* __restrict__ stats) {
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -178,6 +225,31 @@ extern "C" int catppo_adv_moments_parts(catppo_ctx* ctx, const double* adv_part_
   const int64_t n_mb = cdiv64(total, minibatch);
   hipLaunchKernelGGL(adv_moments_parts_kernel, dim3((unsigned)n_mb), dim3(64), 0, static_cast<hipStream_t>(stream),
                      adv_part_g, parts_per_mb, total, minibatch, moments);
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+extern "C" int catppo_adv_moments_keyed(catppo_ctx* ctx, const void* advantages, int adv_dtype,
+                                        const catppo_iter_state* state, int32_t n_epochs, int64_t total,
+                                        int64_t minibatch, double* parts_scratch, double* moments, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, advantages && state && parts_scratch && moments);
+  CATPPO_CHECK_ARG(ctx, adv_dtype == CATPPO_F32 || adv_dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, n_epochs >= 1 && n_epochs <= 65535 && total >= 1 && total < (int64_t(1) << 31) && minibatch >= 1);
+  const int64_t n_mb = cdiv64(total, minibatch);
+  const int64_t parts = cdiv64(minibatch, 64);
+  CATPPO_CHECK_ARG(ctx, n_mb <= 65535 && parts <= (int64_t(1) << 30));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)parts, (unsigned)n_mb, (unsigned)n_epochs);
+  if (adv_dtype == CATPPO_F16)
+    hipLaunchKernelGGL(adv_parts_keyed_kernel<_Float16>, grid, dim3(64), 0, s, static_cast<const _Float16*>(advantages),
+                       state, total, minibatch, (int)parts, parts_scratch);
+  else
+    hipLaunchKernelGGL(adv_parts_keyed_kernel<float>, grid, dim3(64), 0, s, static_cast<const float*>(advantages), state,
+                       total, minibatch, (int)parts, parts_scratch);
+  CATPPO_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(adv_moments_parts_epochs_kernel, dim3((unsigned)(n_mb * n_epochs)), dim3(64), 0, s,
+                     (const double*)parts_scratch, (int)parts, (int)n_mb, total, minibatch, moments);
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }

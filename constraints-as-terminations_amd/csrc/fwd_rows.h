@@ -87,8 +87,11 @@ struct Layer {
   // and slab s+3 is requested (a request past the last slab reads the weight rows / the bias that follow: in bounds by
   // the plan's check, never multiplied).  No branch inside: the loop body is straight-line code.
   template <int NB, bool NEXT, bool REFILL>
-  __device__ __forceinline__ void slab(const float* __restrict__ as, const int ld, const float* __restrict__ bs,
-                                       float* __restrict__ mine, const float* __restrict__ bn, const int s,
+  // (`bs`, `mine` and `bn` point into the SAME wave-private ring - a REFILL slab reads slot `bs` and then overwrites it
+  // through `mine` - so none of them may be __restrict__: the order "last fragment read, then ds_write" is kept by the
+  // sched_barriers below and by the in-order LDS issue of a wave, not by an aliasing promise)
+  __device__ __forceinline__ void slab(const float* __restrict__ as, const int ld, const float* bs,
+                                       float* mine, const float* bn, const int s,
                                        float4 (&fa)[2][T], float4 (&fb)[2], f32x16 (&acc)[T], const int lane) {
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {

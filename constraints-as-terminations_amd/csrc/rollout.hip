@@ -679,6 +679,23 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
     CATPPO_CHECK_ARG(ctx, a->sim_state != nullptr && a->sim_row_bytes >= 16 && a->sim_row_bytes % 16 == 0);
     CATPPO_CHECK_ARG(ctx, (reinterpret_cast<uintptr_t>(a->sim_src) & 15) == 0 && (reinterpret_cast<uintptr_t>(a->sim_state) & 15) == 0);
   }
+  if (a->sim_src != nullptr) {
+    // nothing this launch WRITES may live inside the state block: the row copy would race with it and the slab would win
+    // (a third-party simulator that keeps e.g. its reward or episode_length buffer inside its state tensor must pass
+    // sim_src = NULL and update the block itself)
+    auto inside = [&](const void* q, int64_t bytes) {
+      const char* c = static_cast<const char*>(q);
+      return c != nullptr && c < st_lo + st_bytes && c + bytes > st_lo;
+    };
+    const bool clash = inside(a->action, a->N * a->A * 4) || inside(a->prev_action, a->N * a->A * 4) ||
+                       inside(a->episode_length, a->N * 8) || inside(a->reward, a->N * 4) ||
+                       inside(a->cstr, a->N * (int64_t)a->K * 4) || inside(a->time_outs, a->N) ||
+                       inside(a->terminated, a->N) || inside(a->reset, a->N) || inside(a->xchg, 4);
+    if (clash)
+      return catppo_fail(ctx, CATPPO_E_ARG, "catppo_rollout_pre: an OUTPUT of the step (action / prev_action / "
+                         "episode_length / reward / cstr / time_outs / terminated / reset / xchg) lies inside the simulator "
+                         "state block that sim_src is copied over; pass sim_src = NULL and advance the state yourself");
+  }
   auto rebase = [&](const float* q) -> const float* {
     const char* c = reinterpret_cast<const char*>(q);
     if (a->sim_src == nullptr || c == nullptr || c < st_lo || c >= st_lo + st_bytes) return q;

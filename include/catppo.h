@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CATPPO_VERSION 400 /* 0.4.0 */
+#define CATPPO_VERSION 500 /* 0.5.0 */
 
 #define CATPPO_OK 0
 #define CATPPO_E_ARG (-1)     /* bad argument */
@@ -446,6 +446,15 @@ int catppo_ppo_gather_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const f
                          const float* b_values_n, const int64_t* inds, const catppo_iter_state* state, int32_t epoch,
                          int64_t total, int64_t M, float* x_g, float* act_g, float* scal_g, double* adv_part_g,
                          int64_t* inds_out, void* stream);
+/* ABI 0.5: the moments of ALL `n_epochs` keyed permutations of an iteration (catppo_ppo_gather_ex with `state`) in one
+ * call, before the first gather: moments[(e * n_mb + m)] = {sum, sum of squares, rows} of minibatch m of epoch e, so an
+ * env-sharded run exchanges the advantage statistics of an iteration with ONE all-reduce instead of one per epoch.
+ * `parts_scratch`: n_epochs * n_mb * ceil(minibatch / 64) * 2 doubles.  Chunking and summation order are the
+ * gather's: bit-identical to catppo_adv_moments_parts on the partials of the epoch's own gather.  `advantages`: the
+ * (total,) plane, CATPPO_F32 or CATPPO_F16.   replaces: cleanrl/ppo.py:314-318 across ranks and epochs. */
+int catppo_adv_moments_keyed(catppo_ctx* ctx, const void* advantages, int adv_dtype, const catppo_iter_state* state,
+                             int32_t n_epochs, int64_t total, int64_t minibatch, double* parts_scratch,
+                             double* moments, void* stream);
 
 /* ---- fp16 rollout planes (BASELINE config 5) ------------------------------------------------------------------
  * catppo_rollout_store_ex: catppo_rollout_store with the three destination rows in `dtype`.

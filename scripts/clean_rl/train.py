@@ -92,8 +92,10 @@ def _main(args_cli):
         # dmabuf IPC for RCCL on this platform; must be in the environment before the first HIP call of the process
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # rendezvous on gloo (CPU): the process's ONLY RCCL communicator is libcatppo's own, created by PPOTrainer
+        # (cat_envs.parallel.init_native_comm); cf. scripts/skrl/train.py:116-117 for the reference's distributed set-up
+        from cat_envs import parallel
+        parallel.init_rendezvous(local)
         if args_cli.device is None:
             args_cli.device = f"cuda:{local}"
 

@@ -173,6 +173,66 @@ def gen_terms():
          **{k: t2n(v) for k, v in out.items()})
 
 
+def gen_terms_scale():
+    """the norm-based terms (C8, C13) and everything a norm gates (C7 contact, C9 / C10 / C15) at
+    4096 envs x 4 steps with the norms planted AT their limits (streams.sim_state_at_the_limits).  Stored: the reference's
+    outputs of step 0 in full, and for every step the packed violation masks `c > 0` and a sha256 of the raw fp32 bytes
+    (a bit-exact consumer checks the hash; one that is not gets the step-0 values to count ulps against).  Also records,
+    on the way, that torch.norm over a short last dimension IS the fp32 FMA chain the oracle / kernels restate."""
+    import hashlib
+    _, _, cs, _ = R.load_ref_cat()
+    from isaaclab.managers import SceneEntityCfg
+    n, steps = 4096, 4
+    states = S.sim_state_at_the_limits(91, n, steps)
+    feet = SceneEntityCfg("contact_forces", body_ids=[3, 6, 9, 12])
+    upper = SceneEntityCfg("contact_forces", body_ids=[0, 2, 5, 8, 11])
+    alljoints = SceneEntityCfg("robot", joint_ids=slice(None))
+    names = ("base_orientation", "foot_contact_force", "contact", "air_time", "n_foot_contact", "no_move")
+    rec = {k: [] for k in names}
+    chain_mismatch = 0
+    for st in states:
+        tt = {k: (torch.from_numpy(v) if isinstance(v, np.ndarray) else v) for k, v in st.items()}
+        robot = types.SimpleNamespace(data=types.SimpleNamespace(
+            joint_pos=tt["joint_pos"], default_joint_pos=tt["default_joint_pos"], joint_vel=tt["joint_vel"],
+            joint_acc=tt["joint_acc"], applied_torque=tt["applied_torque"],
+            projected_gravity_b=tt["projected_gravity_b"], root_pos_w=tt["root_pos_w"]))
+        sensor = types.SimpleNamespace(
+            data=types.SimpleNamespace(net_forces_w_history=tt["net_forces_w_history"],
+                                       last_air_time=tt["last_air_time"]),
+            compute_first_contact=lambda dt, tt=tt: tt["first_contact"])
+        env = types.SimpleNamespace(
+            scene={"robot": robot, "contact_forces": sensor},
+            command_manager=types.SimpleNamespace(get_command=lambda name, tt=tt: tt["command"]),
+            action_manager=types.SimpleNamespace(_action=tt["action"], _prev_action=tt["prev_action"]),
+            step_dt=st["step_dt"])
+        out = {
+            "base_orientation": cs.base_orientation(env, 0.1, SceneEntityCfg("robot")),
+            "foot_contact_force": cs.foot_contact_force(env, 50.0, feet),
+            "contact": cs.contact(env, upper),
+            "air_time": cs.air_time(env, 0.25, 0.1, feet),
+            "n_foot_contact": cs.n_foot_contact(env, 2, 0.5, feet),
+            "no_move": cs.no_move(env, 0.1, 4.0, alljoints),
+        }
+        for k in names:
+            rec[k].append(np.ascontiguousarray(t2n(out[k]).astype(np.float32).reshape(n, -1)))
+        # torch.norm == fp32 FMA chain (what oracle/cat_oracle.py:_norm_last and csrc/terms_eval.h:norm3 restate)
+        f = st["net_forces_w_history"]
+        w = np.longdouble
+        acc = (f[..., 0] * f[..., 0]).astype(np.float32)
+        for i in (1, 2):
+            acc = (f[..., i].astype(w) * f[..., i].astype(w) + acc.astype(w)).astype(np.float32)
+        chain_mismatch += int((np.sqrt(acc) != torch.norm(tt["net_forces_w_history"], dim=-1).numpy()).sum())
+    assert chain_mismatch == 0, chain_mismatch
+    payload = {"seed": 91, "n_envs": n, "steps": steps, "norm_is_fma_chain_mismatches": chain_mismatch,
+               "input_checksum": S.checksum(*[np.asarray(v) for st in states for v in st.values()])}
+    for k in names:
+        payload[k + "_step0"] = rec[k][0]
+        payload[k + "_mask_bits"] = np.stack([np.packbits(a > 0) for a in rec[k]])
+        payload[k + "_sha256"] = np.array([hashlib.sha256(a.tobytes()).hexdigest() for a in rec[k]])
+        payload[k + "_at_zero"] = np.array([int((a == 0).sum()) for a in rec[k]])
+    save("terms_scale", **payload)
+
+
 # ------------------------------------------------------------------------------ env finish
 def gen_envfinish():
     rs = np.random.RandomState(5)
@@ -599,6 +659,8 @@ def main():
         return gen_skrl_gae()
     if sys.argv[1:] == ["rlg_play_steps"]:
         return gen_rlg_play_steps()
+    if sys.argv[1:] == ["terms_scale"]:
+        return gen_terms_scale()
     print("CaT streams")
     gen_cat("small", 101, 7, S.CAT_TERMS_SMALL, [0.25, 1.0, 0.25, 1.0, 0.5], 16,
             curriculum_at=8, reset_at={5, 11})
@@ -608,6 +670,7 @@ def main():
     gen_curriculum()
     print("terms / envfinish / rms / agent")
     gen_terms()
+    gen_terms_scale()
     gen_envfinish()
     gen_rms()
     gen_agent()

@@ -91,6 +91,59 @@ def sim_state(seed: int, n_envs: int, n_joints: int = 12, n_bodies: int = 13, hi
     }
 
 
+def sim_state_at_the_limits(seed: int, n_envs: int, steps: int, force_limit: float = 50.0, grav_limit: float = 0.1,
+                            deadzone: float = 0.1, min_command: float = 0.5):
+    """`steps` fake Solo12 states of `n_envs` envs each (one dict per step, `sim_state` distributions) in which a large
+    share of the vectors that feed a NORM sits at, or within a few ulps of, the limit the reference compares the norm
+    with (cat/constraints.py:113-119 `||g_xy|| - limit`, :201-211 `max_h ||F|| - limit`, :129-147 / :163-181 / :226-235
+    the command-norm gates) - the only inputs for which a last-bit difference in the norm changes `c > 0`, i.e. the
+    termination mask.  Planted per step: exact Pythagorean vectors (the norm is exact in every summation order),
+    random directions scaled to the limit in fp64 and rounded to fp32 (the norm lands within ~2 ulp of the limit, on
+    either side), and the same nudged by +-1..3 ulp per component."""
+    out = []
+    for k in range(steps):
+        st = sim_state(seed + 1000 * k, n_envs)
+        rs = np.random.RandomState(seed + 1000 * k + 7)
+        n = n_envs
+
+        def at_norm(shape_prefix, dim, target):
+            v = rs.standard_normal(shape_prefix + (dim,))
+            v *= target / np.linalg.norm(v, axis=-1, keepdims=True)
+            v32 = v.astype(F32)
+            nudge = rs.randint(-3, 4, size=v32.shape)
+            sel = rs.rand(*v32.shape) < 0.5
+            i32 = v32.view(np.int32) + np.where(sel, nudge, 0).astype(np.int32)
+            return i32.view(F32)
+
+        # contact forces: feet bodies 3, 6, 9, 12 (and the upper-body ids the contact term reads) in half of the envs
+        f = st["net_forces_w_history"]
+        H, B = f.shape[1], f.shape[2]
+        rows = rs.rand(n) < 0.5
+        near = np.abs(at_norm((n, H, B), 3, force_limit))
+        f[rows] = near[rows]
+        trip = np.array([[30.0, 40.0, 0.0], [0.0, 30.0, 40.0], [40.0, 0.0, 30.0], [0.0, 0.0, 50.0], [14.0, 48.0, 0.0]], F32)
+        exact = rs.rand(n) < 0.1
+        f[exact] = trip[rs.randint(0, len(trip), size=(int(exact.sum()), H, B))] * F32(force_limit / 50.0)
+        # the contact terms compare the same norms with 1.0
+        one = rs.rand(n) < 0.15
+        f[one] = np.abs(at_norm((n, H, B), 3, 1.0))[one]
+        # projected gravity: ||g_xy|| at grav_limit in half of the envs (z completes the unit vector)
+        g = st["projected_gravity_b"]
+        rows = rs.rand(n) < 0.5
+        gxy = at_norm((n,), 2, grav_limit)
+        g[rows, :2] = gxy[rows]
+        g[rows, 2] = -np.sqrt(np.maximum(0.0, 1.0 - (gxy[rows].astype(np.float64) ** 2).sum(1))).astype(F32)
+        exact = rs.rand(n) < 0.05
+        g[exact, 0], g[exact, 1] = F32(0.6 * grav_limit), F32(0.8 * grav_limit)
+        # command: ||cmd[:3]|| at the two gates
+        c = st["command"]
+        for target, share in ((deadzone, 0.3), (min_command, 0.3)):
+            rows = rs.rand(n) < share
+            c[rows, :3] = at_norm((n,), 3, target)[rows]
+        out.append(st)
+    return out
+
+
 def soft_dones(rs, shape):
     """float dones in [0,1]: mostly exact 0, some exact 1, some fractional (CaT probabilities)."""
     u = rs.rand(*shape)

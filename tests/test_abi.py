@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/catppo.h but not exported"
     assert set(names) == set(native.EXPORTS), set(names) ^ set(native.EXPORTS)
-    assert lib.catppo_version() == 400
+    assert lib.catppo_version() == 500
 
 
 def test_layout_matches_reference_parameter_count():

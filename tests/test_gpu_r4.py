@@ -59,10 +59,10 @@ def test_agent_forward_on_the_device_vs_reference_golden(golden):
 _OVERLAP_CODE = r"""
 import os, sys, torch, numpy as np
 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['TEST_PORT'], RANK='0', WORLD_SIZE='1')
-torch.cuda.set_device(0)
-torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', 0))
 import smoke_impl
 from cat_envs import parallel
+parallel.init_rendezvous(0)          # gloo rendezvous: libcatppo's communicator is the only RCCL communicator of the process
+assert torch.distributed.get_backend() == 'gloo'
 from cat_envs.shim import make
 from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
 assert parallel.active()
@@ -114,10 +114,10 @@ def test_gradient_buckets_reduced_beside_the_backward_pass_world_of_one():
 _FALLBACK_CODE = r"""
 import os, sys, torch, numpy as np
 os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['TEST_PORT'], RANK='0', WORLD_SIZE='1')
-torch.cuda.set_device(0)
-torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', 0))
 import smoke_impl
 from cat_envs import parallel
+parallel.init_rendezvous(0)          # gloo rendezvous: libcatppo's communicator is the only RCCL communicator of the process
+assert torch.distributed.get_backend() == 'gloo'
 from cat_envs.shim import make
 from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
 out = []
@@ -149,9 +149,10 @@ print("FALLBACK-OK")
 
 
 def test_failed_graph_replay_falls_back_to_eager_launches_and_says_so():
-    """graph replay with RCCL inside is the default at every world size; when the capture or
-    the first replay fails in an env-sharded run the update phase continues eagerly (bit-identical result) and the
-    reason is kept in ``PPOTrainer.graph_fallback`` (bench.py prints it)."""
+    """when the capture or the first replay of the update-phase graph fails in an env-sharded run
+    the update phase continues eagerly (bit-identical result) and the reason is kept in ``PPOTrainer.graph_fallback``
+    (bench.py prints it).  (Round 5: with REAL peers graph + collectives is opt-in, ``CATPPO_GRAPH_COMM=1``; a forced
+    world of one - this test - keeps it on.)"""
     r = _run_code(_FALLBACK_CODE)
     assert r.returncode == 0 and "FALLBACK-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     assert "falling back to eager launches" in r.stderr
