@@ -128,15 +128,20 @@ struct Layer {
     }
   }
 
+  // ZERO = false: the accumulators continue a contraction begun by an earlier call (fwd_rows_wide.h: a 512-wide input
+  // consumed in 256-column chunks - the MFMA chain per element simply goes on, k ascending)
+  template <bool ZERO = true>
   __device__ __forceinline__ void loop(const float* __restrict__ tile, const int ld, float* __restrict__ wring,
                                        const int K, f32x16 (&acc)[T], const int lane) {
     const int l31 = lane & 31, h = lane >> 5;
     const int nblk = K >> 3;                         // 8-k blocks of the contraction (K % 16 == 0)
     const int n_slabs = (nblk + 3) >> 2;             // 32-k slabs; the last one may hold 2 blocks
+    if (ZERO) {
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+      for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
     const float* ap = tile + l31 * ld + 4 * h;       // A fragments: row l31 (+ 32 t), k = 32 s + 8 blk + 4 h ..
     float* const w0 = wring;
     float* const w1 = wring + kSlot;

@@ -1004,6 +1004,8 @@ __global__ __launch_bounds__(rowsfwd::kThreads) void rows_fwd_kernel(const Fused
   }
 }
 
+#include "fwd_rows_wide.h"
+
 #ifdef FUSED_TL
 extern "C" int catppo_debug_fused_tl(void* buf) {     // timeline builds only: not part of include/catppo.h
   unsigned long long* pbuf = static_cast<unsigned long long*>(buf);
@@ -2113,6 +2115,76 @@ bool rows_fwd_launch_rollout(const FusedFwdArgs& fa, size_t lds, int64_t rows, i
   return true;
 }
 
+// rows_fwd_wide_kernel (fwd_rows_wide.h) applies when: fp32 MFMA, the first layer is 128 / 256 / 512 wide (512: consumed
+// in two 256-column chunks by the layer above, which must be computed here too), every other computed layer 128 / 256
+// wide, the padded observation width <= 64 (the observation tile persists next to the activation tile), and the run-ahead
+// weight requests stay inside the flat parameter buffer.  Networks whose computed layers are ALL 256 wide keep
+// rows_fwd_kernel (one in-place tile: also fits wide observations).
+bool rows_wide_plan(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, int n_layers, int R, FusedFwdArgs* fa,
+                    size_t* lds, int* nch) {
+  if (sh->mfma_bf16 != 0 || n_layers < 1 || n_layers > 3 || n_layers > sh->n_hidden) return false;
+  if (L.obs_pad > 64) return false;
+  const int w0 = sh->hidden[0];
+  if (w0 != 128 && w0 != 256 && w0 != 512) return false;
+  if (w0 == 512 && n_layers < 2) return false;
+  for (int l = 1; l < n_layers; ++l)
+    if (sh->hidden[l] != 128 && sh->hidden[l] != 256) return false;
+  *nch = w0 == 512 ? 2 : 1;
+  fa->Dp = L.obs_pad, fa->n_hidden = n_layers;
+  fa->ld0 = rowsfwd::kTileLd, fa->ld1 = L.obs_pad + 4;      // (w + 4) / 4 odd for Dp = 16 / 32 / 48 / 64: conflict-free b128 rows
+  for (int l = 0; l < n_layers; ++l) fa->hidden[l] = sh->hidden[l];
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l <= sh->n_hidden; ++l) fa->off_w[net][l] = L.off_w[net][l], fa->off_b[net][l] = L.off_b[net][l];
+  // over-reads: `pre` reads k 32..63 of every first-layer row (a 48-wide row: 16 floats into the next row / the bias),
+  // the long contractions request up to three 32-k slabs past the end of a weight row range (<= 160 floats past a matrix)
+  for (int net = 0; net < 2; ++net)
+    for (int l = 0; l < n_layers; ++l)
+      if (L.off_w[net][l] + (int64_t)sh->hidden[l] * L.in_dim[l] + 160 > L.n_flat) return false;
+  *lds = R == 64 ? rowsfwd::wide_lds_bytes<64>(fa->ld1) : rowsfwd::wide_lds_bytes<32>(fa->ld1);
+  return *lds <= 160 * 1024;
+}
+
+template <int R, bool TRAIN, int NETS, int NL, int NCH>
+void rows_wide_launch_k(const FusedFwdArgs& a, size_t lds, int64_t tiles, int nets, hipStream_t s) {
+  auto kern = rows_fwd_wide_kernel<R, TRAIN, NETS, NL, NCH>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kern, dim3((unsigned)tiles, NETS == 2 ? 1 : nets), dim3(rowsfwd::kThreads), lds, s, a);
+}
+
+template <int R, bool TRAIN, int NETS>
+bool rows_wide_dispatch(const FusedFwdArgs& a, size_t lds, int64_t tiles, int nets, int nch, hipStream_t s) {
+  const int nl = a.n_hidden;
+  if (nch == 1) {
+    if (nl == 1) rows_wide_launch_k<R, TRAIN, NETS, 1, 1>(a, lds, tiles, nets, s);
+    else if (nl == 2) rows_wide_launch_k<R, TRAIN, NETS, 2, 1>(a, lds, tiles, nets, s);
+    else if (nl == 3) rows_wide_launch_k<R, TRAIN, NETS, 3, 1>(a, lds, tiles, nets, s);
+    else return false;
+  } else {
+    if (nl == 2) rows_wide_launch_k<R, TRAIN, NETS, 2, 2>(a, lds, tiles, nets, s);
+    else if (nl == 3) rows_wide_launch_k<R, TRAIN, NETS, 3, 2>(a, lds, tiles, nets, s);
+    else return false;
+  }
+  return true;
+}
+
+// training (R = 64, activations stored)
+bool rows_wide_launch_train(const FusedFwdArgs& fa, size_t lds, int nch, int64_t rows, int n_cu, hipStream_t s) {
+  FusedFwdArgs a = fa;
+  const int64_t tiles = cdiv64(rows, 64);
+  static const int force_nets = env_int("CATPPO_ROWS_NETS", 0);
+  a.nets_per_wg = force_nets ? force_nets : (tiles >= n_cu ? 2 : 1);
+  if (a.nets_per_wg == 2) return rows_wide_dispatch<64, true, 2>(a, lds, tiles, 2, nch, s);
+  return rows_wide_dispatch<64, true, 1>(a, lds, tiles, 2, nch, s);
+}
+
+// rollout (R = 32, heads): one workgroup per (tile, network)
+bool rows_wide_launch_rollout(const FusedFwdArgs& fa, size_t lds, int nch, int64_t rows, int nets, hipStream_t s) {
+  FusedFwdArgs a = fa;
+  a.nets_per_wg = 1;
+  return rows_wide_dispatch<32, false, 1>(a, lds, cdiv64(rows, 32), nets, nch, s);
+}
+
 // rollout policy step shared by catppo_policy_act / _ex / _rng and catppo_value / _ex
 int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
                 const float* eps, const float* given_action, float* action, float* logprob, void* value,
@@ -2142,6 +2214,28 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
       rows_fwd_launch_rollout(ra, rlds, N, critic_only ? 1 : 2, s);
       CATPPO_CHECK_LAUNCH(ctx);
       return CATPPO_OK;
+    }
+  }
+  {
+    // round 5: networks that are not 256 wide throughout (the reference's 512 / 256 / 128) - rows_fwd_wide_kernel<32>;
+    // CATPPO_ROWS_WIDE=0 / CATPPO_ROWS_WIDE_ROLLOUT=0 fall back to fused_fwd_kernel (A/B)
+    static const int wide_on = env_int("CATPPO_ROWS_WIDE", 1) && env_int("CATPPO_ROWS_WIDE_ROLLOUT", 1);
+    static const int rr_max = env_int("CATPPO_FUSED_FWD_MAX_ROWS", 4096), rr_min = env_int("CATPPO_FUSED_FWD_MIN_ROWS", 2049);
+    FusedFwdArgs wa{};
+    size_t wlds = 0;
+    int nch = 1;
+    const int hl = shape->hidden[shape->n_hidden - 1];
+    if (wide_on && N <= rr_max && N >= rr_min && (hl == 128 || hl == 256) &&
+        rows_wide_plan(shape, L, shape->n_hidden, 32, &wa, &wlds, &nch)) {
+      wa.x = x, wa.params = params, wa.M = N;
+      wa.net0 = 0;
+      wa.logstd = params + L.off_logstd, wa.eps = eps, wa.given = given_action, wa.A = shape->act_dim;
+      wa.action = action, wa.logprob = logprob, wa.value_out = value, wa.value_f16 = (int)(value_dtype == CATPPO_F16);
+      wa.rng_state = rng_state, wa.rng_step = rng_step, wa.eps_out = eps_out, wa.do_head = 1;
+      if (rows_wide_launch_rollout(wa, wlds, nch, N, critic_only ? 1 : 2, s)) {
+        CATPPO_CHECK_LAUNCH(ctx);
+        return CATPPO_OK;
+      }
     }
   }
   {
@@ -2358,7 +2452,21 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         for (int l = 0; l < nl - 1; ++l) ra.Hout[net][l] = w.H[net][l];
       rows_fwd_launch_train(ra, rlds, M, ctx->n_cu, s);
     } else {
-      forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
+      // round 5: the same for networks that are not 256 wide throughout (reference: 512 / 256 below the 128-wide last
+      // layer): rows_fwd_wide_kernel<64>; CATPPO_ROWS_WIDE=0 keeps the layer-wise launches (A/B)
+      static const int wide_on = env_int("CATPPO_ROWS_WIDE", 1);
+      FusedFwdArgs wa{};
+      size_t wlds = 0;
+      int nch = 1;
+      bool done = false;
+      if (wide_on && rows_fwd_env && M >= rows_fwd_min && M <= (1 << 20) &&
+          rows_wide_plan(shape, L, nl - 1, 64, &wa, &wlds, &nch)) {
+        wa.x = w.xmb, wa.params = params, wa.M = M, wa.net0 = 0, wa.do_head = 0;
+        for (int net = 0; net < 2; ++net)
+          for (int l = 0; l < nl - 1; ++l) wa.Hout[net][l] = w.H[net][l];
+        done = rows_wide_launch_train(wa, wlds, nch, M, ctx->n_cu, s);
+      }
+      if (!done) forward_hidden(shape, L, params, w.xmb, M, w, 0, 2, s, nl - 1);
     }
     CATPPO_CHECK_LAUNCH(ctx);
     Params p{};

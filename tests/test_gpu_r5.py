@@ -235,3 +235,59 @@ def test_norm_based_terms_at_their_limits_at_scale_vs_reference_golden(golden):
                          {f"{name}.{key}": v for name, r in rec.items() for key, v in r.items()}, sizes=dict(n_envs=n, steps=steps),
                          seed=int(g["seed"]))
     assert rec["base_orientation"]["exactly_zero"] > 4000 and rec["foot_contact_force"]["exactly_zero"] > 10000
+
+
+# ------------------------------------------------------------------------------------------ shape-generic row-resident forward
+@pytest.mark.parametrize("D,A,hidden,Bsz,M", [
+    (45, 12, (512, 256, 128), 16384, 16384),      # the reference's Agent at its minibatch size: one workgroup walks both networks
+    (45, 12, (512, 256, 128), 8192, 4133),        # ragged, 65 row tiles: one workgroup per (tile, network), 37-row last tile
+    (45, 12, (512, 256, 128), 16421, 16421),      # ragged AND both networks per workgroup
+    (48, 12, (128, 128), 4160, 4160),             # one computed layer, 128 wide: waves 4-7 idle
+    (48, 12, (256, 128, 128), 8192, 8192),        # 256 then 128 below a 128-wide last layer
+    (30, 5, (512, 128, 256, 128), 4096, 4096),    # chunked first layer consumed by a 128-wide layer, three computed layers
+    (64, 12, (128, 256, 256), 4099, 4099),        # 64-wide observations (two full slabs), 128 -> 256
+    (16, 3, (512, 256, 256), 4096, 4096),         # 16-wide observations (one 2-block slab)
+])
+def test_shape_generic_row_resident_forward_equals_the_layerwise_launches(tmp_path, D, A, hidden, Bsz, M):
+    """rows_fwd_wide_kernel<64> (fwd_rows_wide.h, round 5: a 512-wide first layer produced and consumed in 256-column
+    chunks, 128-wide layers on four waves; reference network cleanrl/ppo.py:78-96) against the layer-wise GEMM launches it
+    replaces: the contraction order per element is the same, so the activations - and with them the whole minibatch
+    gradient and the diagnostics - must be BIT-identical.  Two processes (CATPPO_ROWS_WIDE is read once per process)."""
+    import test_gpu_kernels as TK
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"wide{flag}.npz")
+        code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=0, out=out)
+        env = dict(os.environ, CATPPO_ROWS_WIDE=flag, CATPPO_ROWS_FWD_MIN_ROWS="1")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.abs(outs[1]["grad"]).max() > 0 and np.isfinite(outs[0]["grad"]).all()
+    np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
+    np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
+
+
+def test_shape_generic_row_resident_rollout_forward_equals_the_layerwise_path(tmp_path):
+    """rows_fwd_wide_kernel<32> with heads against the layer-wise rollout forward (cleanrl/ppo.py:104-119) on the reference
+    network and on mixed widths: hidden layers bit-identical by construction, heads sum in another order (2e-6), Philox
+    noise exact.  Window pinned open so that small and ragged batches take the kernel too."""
+    import test_gpu_kernels as TK
+    cases = {"ref": (45, 12, (512, 256, 128), 4096), "ref_ragged": (45, 12, (512, 256, 128), 2049),
+             "ref_tiny": (45, 12, (512, 256, 128), 33), "n128": (48, 7, (128, 128), 300), "one_row": (48, 12, (512, 256), 1),
+             "mixed": (30, 5, (256, 128, 256), 1000), "obs64": (64, 12, (512, 128), 257)}
+    outs = []
+    for env_over in (dict(CATPPO_ROWS_WIDE="1", CATPPO_FUSED_FWD_MIN_ROWS="1"),
+                     dict(CATPPO_ROWS_WIDE="0", CATPPO_FUSED_FWD="0", CATPPO_ROWS_FWD_ROLLOUT="0")):
+        out = str(tmp_path / f"wr{len(outs)}.npz")
+        code = TK._FUSED_FWD_AB.format(root=ROOT, cases=cases, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    f, l = outs
+    for k in f.files:
+        if k.endswith("_e3"):
+            np.testing.assert_array_equal(f[k], l[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(f[k], l[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(l[k]).max())), err_msg=k)
+    assert np.abs(f["ref_act"]).max() > 0 and np.isfinite(f["ref_ragged_lp"]).all()
