@@ -45,6 +45,10 @@ constexpr int BK = 16;             // default contraction slab; kernels take it 
 #define GEMM_PIPE 1                // 0: the round-2 main loop (A/B builds: tools/gpu_ab.sh)
 #endif
 
+#ifndef GEMM_PACKED
+#define GEMM_PACKED 1              // 0: bf16 / split-bf16 operands converted at every use (rounds 1-4) - A/B builds
+#endif
+
 enum Epilogue {
   EPI_BIAS_ELU = 0,  // C = elu(acc + bias[j])                       forward hidden layer
   EPI_MUL_DELU = 1,  // C = acc * elu'(aux[i,j]) (aux = activation)  data gradient
@@ -108,6 +112,211 @@ __device__ __forceinline__ TileId xcd_tile_of(int lin, int tiles, int nz, int le
   const int l = xcd_tile_index(lin, tiles * nz);
   return TileId{l % tiles, l / tiles};
 }
+
+
+// ---- bf16 / split-bf16 operands, split ONCE per workgroup where the slab is staged (round 5) ----------------------------
+// Rounds 1-4 kept fp32 LDS images for every precision and rounded / split each operand element to bf16 at EVERY use: a
+// 128x128 tile's four waves each convert the fragments they read (every element twice), ~3.5 VALU operations per
+// element and use for the split form - the bf16x3 main loops were VALU / LDS bound, not matrix bound.
+// Here the thread that brings a float4 in from memory splits it - hi = bf16(x) (RNE), lo = bf16(x - hi) - and writes
+// bf16 PLANES to LDS; the inner loop is LDS reads + MFMAs only:
+//   K-contiguous operand   plane [rows][16 k] = 32 B rows, the two 16-byte halves of a row swapped in every second group
+//                          of 8 rows (the b128 lane groups of gfx950 - {0-3, 12-15, 20-27}, ... - then hit 16 distinct
+//                          16-byte slots: conflict free WITHOUT padding); a lane's fragment = ONE ds_read_b128 per plane
+//   I-contiguous operand   plane [8 k-pairs][rows] of u32 = {bf16 x(k even, row), bf16 x(k odd, row)}: the staging thread
+//                          loads the SAME four rows at k and k + 1 and packs the pairs (one ds_write_b128 per plane); a
+//                          lane's fragment = four ds_read_b32 per plane (16 for the fp32 image)
+// Slot e of lane half h of v_mfma_f32_32x32x16_bf16 carries k = 8 h + e for A and B alike.  The planes of a (128 + 128)-
+// row slab pair take 128 B per row and buffer pair at most: inside the fp32 allocation of every launcher.
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  bf16x2 v;
+  v[0] = (__bf16)a, v[1] = (__bf16)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float bf16_resid(float x) { return x - (float)(__bf16)x; }
+
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int PREC, int WAVES_M>
+struct PkLoop {
+  static constexpr int NP = PREC == 2 ? 2 : 1;
+  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  static constexpr int A_PLANE = BM * 8, B_PLANE = BN * 8;          // u32 per plane and buffer (16 k x rows x 2 B)
+  // float4 staging registers per thread and slab.  K-contiguous: rows x 4 quads over 256 threads; I-contiguous: one
+  // (k-pair, row quad) job = two float4 (k even / odd), 2 x rows jobs over 256 threads
+  template <int ROWS, bool KC> static constexpr int nreg() { return KC ? ROWS / 64 : (2 * ROWS + 255) / 256 * 2; }
+  static constexpr int A_N = nreg<BM, A_KC>(), B_N = nreg<BN, B_KC>();
+  static_assert((A_KC || BM <= 128) && (B_KC || BN <= 128), "one (k pair, row quad) job per thread for I-contiguous operands");
+  static_assert(NP * 2 * (A_PLANE + B_PLANE) * 4 <= 2 * 4 * ((A_KC ? BM * 20 : 16 * BM) + (B_KC ? BN * 20 : 16 * BN)),
+                "the bf16 planes must fit the fp32 slab allocation of the launchers");
+
+  template <int ROWS, bool KC, int N>
+  static __device__ __forceinline__ void gload(float4 (&r)[N], const float* __restrict__ P, int ld, int row0, int rows_valid,
+                                               int k0, int k_end, bool fast, int tid) {
+    if (KC) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const int f = tid + q * 256, rr = f >> 2, kq = f & 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fast || row0 + rr < rows_valid) v = *reinterpret_cast<const float4*>(P + (int64_t)(row0 + rr) * ld + k0 + 4 * kq);
+        r[q] = v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < N / 2; ++q) {
+        const int j = tid + q * 256, kp = j / (ROWS / 4), iq = j % (ROWS / 4);
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (2 * ROWS >= 256 || j < 2 * ROWS) {                        // (64-row tiles: jobs for the first two waves only)
+          const int gk = k0 + 2 * kp, gi = row0 + 4 * iq;
+          const bool in_i = fast || gi + 3 < rows_valid;
+          if (in_i && (fast || gk < k_end)) v0 = *reinterpret_cast<const float4*>(P + (int64_t)gk * ld + gi);
+          if (in_i && (fast || gk + 1 < k_end)) v1 = *reinterpret_cast<const float4*>(P + (int64_t)(gk + 1) * ld + gi);
+        }
+        r[2 * q] = v0, r[2 * q + 1] = v1;
+      }
+    }
+  }
+
+  template <int ROWS, bool KC, int N>
+  static __device__ __forceinline__ void lstore(uint32_t* __restrict__ planes, const float4 (&r)[N], int tid) {
+    if (KC) {
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const int f = tid + q * 256, rr = f >> 2, kq = f & 3;
+        const int o = rr * 8 + ((((kq >> 1) ^ (rr >> 3)) & 1) << 2) + ((kq & 1) << 1);
+        const float4 v = r[q];
+        u32x2 hi;
+        hi[0] = pk_bf16(v.x, v.y), hi[1] = pk_bf16(v.z, v.w);
+        *reinterpret_cast<u32x2*>(planes + o) = hi;
+        if (NP == 2) {
+          u32x2 lo;
+          lo[0] = pk_bf16(bf16_resid(v.x), bf16_resid(v.y)), lo[1] = pk_bf16(bf16_resid(v.z), bf16_resid(v.w));
+          *reinterpret_cast<u32x2*>(planes + ROWS * 8 + o) = lo;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < N / 2; ++q) {
+        const int j = tid + q * 256, kp = j / (ROWS / 4), iq = j % (ROWS / 4);
+        if (2 * ROWS >= 256 || j < 2 * ROWS) {
+          const float4 a = r[2 * q], b = r[2 * q + 1];
+          u32x4 hi;
+          hi[0] = pk_bf16(a.x, b.x), hi[1] = pk_bf16(a.y, b.y), hi[2] = pk_bf16(a.z, b.z), hi[3] = pk_bf16(a.w, b.w);
+          *reinterpret_cast<u32x4*>(planes + kp * ROWS + 4 * iq) = hi;
+          if (NP == 2) {
+            u32x4 lo;
+            lo[0] = pk_bf16(bf16_resid(a.x), bf16_resid(b.x)), lo[1] = pk_bf16(bf16_resid(a.y), bf16_resid(b.y));
+            lo[2] = pk_bf16(bf16_resid(a.z), bf16_resid(b.z)), lo[3] = pk_bf16(bf16_resid(a.w), bf16_resid(b.w));
+            *reinterpret_cast<u32x4*>(planes + ROWS * 8 + kp * ROWS + 4 * iq) = lo;
+          }
+        }
+      }
+    }
+  }
+
+  // the 8 bf16 (k = 8 h .. 8 h + 7) of operand row `row` out of one plane
+  template <int ROWS, bool KC>
+  static __device__ __forceinline__ bf16x8 frag(const uint32_t* __restrict__ plane, int row, int h) {
+    u32x4 v;
+    if (KC) {
+      v = *reinterpret_cast<const u32x4*>(plane + row * 8 + (((h ^ (row >> 3)) & 1) << 2));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = plane[(4 * h + i) * ROWS + row];
+    }
+    return __builtin_bit_cast(bf16x8, v);
+  }
+
+  static __device__ __forceinline__ void run(const Params& p, const Operands& op, const int i0, const int j0,
+                                             const int k_begin, const int k_end, const bool do_db,
+                                             float* __restrict__ smem, f32x16 (&acc)[TM][TN], float& dbsum) {
+    uint32_t* As = reinterpret_cast<uint32_t*>(smem);                  // [2][NP][A_PLANE]
+    uint32_t* Bs = As + 2 * NP * A_PLANE;                              // [2][NP][B_PLANE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = WAVES_M == 2 ? wave >> 1 : 0, wn = WAVES_M == 2 ? wave & 1 : wave;
+    const int l31 = lane & 31, h = lane >> 5;
+    float4 ra[A_N], rb[B_N];
+    const int n_slabs = (k_end - k_begin + 15) / 16;
+    // every row / column of the tile in bounds and the contraction range a whole number of slabs: unguarded loads
+    const bool fast = (i0 + BM <= p.I) && (j0 + BN <= p.J) && ((k_end - k_begin) % 16 == 0);
+    float dbv[4] = {0.f, 0.f, 0.f, 0.f};                               // EPI_PARTIAL: exact fp32 column sums of A (bias gradient)
+    auto load = [&](int s) {
+      const int k0 = k_begin + 16 * s;
+      gload<BM, A_KC>(ra, op.A, p.lda, i0, p.I, k0, k_end, fast, tid);
+      gload<BN, B_KC>(rb, op.B, p.ldb, j0, p.J, k0, k_end, fast, tid);
+      if (EPI == EPI_PARTIAL && !A_KC) {
+        if (do_db) {
+#pragma unroll
+          for (int q = 0; q < A_N; ++q) dbv[0] += ra[q].x, dbv[1] += ra[q].y, dbv[2] += ra[q].z, dbv[3] += ra[q].w;
+        }
+      }
+    };
+    auto store = [&](int buf) {
+      lstore<BM, A_KC>(As + buf * NP * A_PLANE, ra, tid);
+      lstore<BN, B_KC>(Bs + buf * NP * B_PLANE, rb, tid);
+    };
+    if (n_slabs > 0) {
+      load(0);
+      store(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < n_slabs; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < n_slabs) load(s + 1);                                // in flight under the MFMAs below
+      const uint32_t* a = As + cur * NP * A_PLANE;
+      const uint32_t* b = Bs + cur * NP * B_PLANE;
+      bf16x8 pa[TM], pb[TN], la[TM], lb[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t) {
+        pa[t] = frag<BM, A_KC>(a, wm * WM + t * 32 + l31, h);
+        if (NP == 2) la[t] = frag<BM, A_KC>(a + A_PLANE, wm * WM + t * 32 + l31, h);
+      }
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        pb[t] = frag<BN, B_KC>(b, wn * WN + t * 32 + l31, h);
+        if (NP == 2) lb[t] = frag<BN, B_KC>(b + B_PLANE, wn * WN + t * 32 + l31, h);
+      }
+      if (NP == 2) {                                                   // small terms first (order of rounds 2-4)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la[tm], pb[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[tm], lb[tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[tm], pb[tn], acc[tm][tn], 0, 0, 0);
+      if (s + 1 < n_slabs) store(cur ^ 1);
+      __syncthreads();
+    }
+    if (EPI == EPI_PARTIAL && !A_KC) {
+      // bias gradient: the column sums of A over this split, exact fp32, from the values the staging threads saw: thread
+      // (k pair, row quad) holds the sums of its two k rows over all slabs; the 8 k-pair groups are added in fixed order
+      if (do_db) {                                                     // workgroup-uniform
+        if (2 * BM >= 256 || tid < 2 * BM) {
+          const int kp = tid / (BM / 4), iq = tid % (BM / 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) smem[kp * BM + 4 * iq + i] = dbv[i];
+        }
+        __syncthreads();
+        if (tid < BM) {
+          float sum = 0.0f;
+#pragma unroll
+          for (int kp = 0; kp < 8; ++kp) sum += smem[kp * BM + tid];
+          dbsum = sum;
+        }
+        __syncthreads();
+      }
+    }
+  }
+};
 
 // One workgroup's tile.  `wg` = tile index inside the problem (j fastest), `bz` = net + nets * split; both come from
 // xcd_tile_of.
@@ -255,11 +464,20 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   const bool do_db = (EPI == EPI_PARTIAL) && op.dbias != nullptr && j0 == 0;
 
   const int n_slabs = (k_end - k_begin + BK - 1) / BK;
-  if (n_slabs > 0) {
-    gload(k_begin, std::false_type{});
-    lstore(0);
+  // bf16 / split-bf16 operands: planes split at staging time, their own slab loop (PkLoop above)
+  // Measured (profiles/r5_ab_packed_*.txt, interleaved A/B against the per-use conversion): split-bf16 pair launch 53.6 ->
+  // 49.9 us, 128x128 forward 27.0 -> 25.1 us, minibatch group 209.2 -> 200.5 us.  NOT used for (a) plain bf16 operands:
+  // one v_cvt_pk per two elements was never the bound there - the bf16 pair launch moves ~185 MB in 36.8 us = 5.0 TB/s, it
+  // sits on the HBM roofline, and the planes' two-row loads cost it 1.4 us; (b) 64-row I-contiguous tiles (the first
+  // layer's latency-bound weight gradient: only half the threads have a (k pair, row quad) job, 13.0 -> 19.0 us).
+  constexpr bool kPacked = PREC == 2 && GEMM_PACKED && BK == 16 && (A_KC || BM >= 128) && (B_KC || BN >= 128);
+  if constexpr (!kPacked) {
+    if (n_slabs > 0) {
+      gload(k_begin, std::false_type{});
+      lstore(0);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
   // data gradient: the activation the epilogue multiplies with does not depend on the contraction; with one
   // accumulator tile per wave (16 values per lane) fetch it now so its HBM latency hides behind the main loop
@@ -451,8 +669,12 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   }
   };
   constexpr bool kPipedLoop = PREC == 0 && BK == 16 && GEMM_PIPE && A_KC && B_KC;
-  if (kPipedLoop && interior && (k_end - k_begin) % BK == 0) main_loop(std::true_type{});
-  else main_loop(std::false_type{});
+  if constexpr (kPacked) {
+    PkLoop<BM, BN, A_KC, B_KC, EPI, PREC, WAVES_M>::run(p, op, i0, j0, k_begin, k_end, do_db, smem, acc, dbsum);
+  } else {
+    if (kPipedLoop && interior && (k_end - k_begin) % BK == 0) main_loop(std::true_type{});
+    else main_loop(std::false_type{});
+  }
 
 #ifdef GEMM_TIMELINE
   if (threadIdx.x == 0) {
