@@ -80,6 +80,20 @@ def fwd_macs(obs_dim, hidden, act_dim=12):
     return 2 * body + hidden[-1] * (act_dim + 1)
 
 
+def executed_macs(obs_pad, hidden, head_pad=16):
+    """multiply-accumulates per sample the MATRIX PIPE executes in one forward + backward of both networks, as opposed to
+    the algorithmic 3 x forward of SURVEY 8(d): observations padded to a multiple of 16, the first layer's data gradient
+    never computed (nobody needs d loss / d obs), head products run as 16-output MFMA tiles inside fwd_head_kernel
+    (forward, head weight gradient, dZ of the last layer)"""
+    dims = [obs_pad, *hidden]
+    body = sum(i * o for i, o in zip(dims[:-1], dims[1:]))          # one network
+    heads = head_pad * hidden[-1]                                    # one network, one of the three head products
+    fwd = 2 * (body + heads)
+    dw = 2 * (body + heads)
+    dx = 2 * (body - obs_pad * hidden[0] + heads)
+    return fwd + dw + dx
+
+
 def csrc_hash():
     """identity of the kernel sources: PMC traffic summaries under profiles/ are stamped with it"""
     h = hashlib.sha256()
@@ -191,7 +205,7 @@ def pmc_traffic(workload, tag):
 
 
 GROUP_KERNELS = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel",
-                 "rows_fwd_kernel", "dw_fold_kernel")
+                 "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel")
 
 
 def profiled_group_us(workload, tag):
@@ -216,7 +230,8 @@ def profiled_group_us(workload, tag):
     for r in rows:
         if not any(k in r["kernel"] for k in GROUP_KERNELS):
             continue
-        if "<64, 64, true, true, 0, 64" in r["kernel"] or "policy_fwd" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"]:
+        if "<64, 64, true, true, 0, 64" in r["kernel"] or "policy_fwd" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"] \
+                or "rows_fwd_wide_kernel<32" in r["kernel"]:
             continue                                   # rollout-only launches (<= 4096 rows)
         if "<64, 64, true, true, 0" in r["kernel"]:    # first-layer forward: the rollout uses the same kernel on fewer rows
             if blocks(r) < max(blocks(q) for q in rows if q["kernel"] == r["kernel"]):
@@ -248,6 +263,67 @@ def gae_roofline(nat, T, N, reps=50, mode=None):
     byt = 24.0 * T * N + 12.0 * N
     return {"T": T, "N": N, "us": us, "GBps": byt / us / 1e3, "frac": byt / us / 1e3 / HBM_PEAK_GBPS,
             "mode": {None: "serial_exact", native.GAE_SCAN: "scan", native.GAE_SERIAL: "serial_exact"}[mode]}
+
+
+def time_group_eager(trainer, reps=12, skip=2):
+    """average device time (us) of catppo_ppo_minibatch_grad_packed on the data of the trainer's last iteration: HIP events
+    around `reps` eager calls on the current stream, the first `skip` dropped"""
+    nat = trainer.nat
+    trainer._update_buffers()
+    # (env-sharded runs normalise advantages with the statistics of the GLOBAL minibatch: hand the kernel the first pair
+    # the last iteration computed)
+    adv_stats = trainer._adv_stats_all[0] if trainer.hp.adv_stats_external else None
+    ev = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        nat.ppo_minibatch_grad_packed(trainer.agent.shape, trainer.hp, trainer.agent.flat, trainer._x_g, trainer._act_g,
+                                      trainer._scal_g, trainer._advp_g, trainer.M, trainer.agent.value_rms.running_mean,
+                                      trainer.agent.value_rms.running_var, adv_stats, trainer.grad, trainer.diag)
+        e1.record()
+        ev.append((e0, e1))
+    torch.cuda.synchronize()
+    ev = ev[skip:]
+    return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3, len(ev)
+
+
+def secondary_record(a, w, dev_index, steps, warmup):
+    """The same workload with split-bf16 GEMM operands (`mlp_precision="bf16x3"`: hi/lo bf16 planes, three bf16 MFMAs per
+    product, ~16 mantissa bits - wider than the TF32 arithmetic the reference enables for these GEMMs,
+    /root/reference/scripts/clean_rl/train.py:86-87; passes the fp32 parity bars of tests/test_gpu_r2_features.py), as a
+    SECONDARY record next to the fp32 headline: a fresh trainer built and timed after the headline's timed region."""
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        env, tr, cfg = build(a.workload, a.seed, dev_index, "bf16x3", 1, 0, {})
+    for _ in range(warmup):
+        tr.run_iteration(log=True)
+    tr.time_phases = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.run_iteration(log=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    phases = tr.phase_summary()
+    grp_us, n_ev = time_group_eager(tr)
+    macs = fwd_macs(w["obs_dim"], w["hidden"])
+    flops = 3 * 2 * macs * tr.M
+    ach = flops / grp_us / 1e6
+    traffic, src, note = pmc_traffic(a.workload + "_bf16x3", a.profile_tag)
+    prof_us, prof_src = profiled_group_us(a.workload + "_bf16x3", a.profile_tag)
+    return {"dtype": "bf16x3 (split-bf16 GEMM operands = 16 mantissa bits, f32 accumulate/params/activations; meets the "
+                     "f32 parity tolerances)",
+            "value": tr.N * w["num_steps"] * steps / dt, "unit": "env-steps/s", "ms_per_step": 1e3 * dt / steps,
+            "steps": steps, "warmup": warmup, "phases_device_ms": phases,
+            "measured": "after the timed region of the headline, fresh trainer, same workload / seed",
+            "roofline": {"bound": "mfma", "achieved": 3.0 * ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": 3.0 * ach / MFMA_BF16_PEAK_TFLOPS, "algorithmic_tflops": ach,
+                         "executed_over_algorithmic_flops": 3.0, "avg_launch_us": grp_us, "launches_timed": n_ev,
+                         "traffic": traffic, "traffic_source": src, "traffic_note": note,
+                         "hbm_GBps": None if not traffic else traffic / grp_us / 1e3,
+                         "hbm_frac": None if not traffic else traffic / grp_us / 1e3 / HBM_PEAK_GBPS,
+                         "dominant_kernel_us_profiled": prof_us, "profiled_source": prof_src,
+                         "frac_profiled": None if not prof_us else 3.0 * flops / prof_us / 1e6 / MFMA_BF16_PEAK_TFLOPS}}
 
 
 def self_launch(n_ranks: int) -> int:
@@ -305,7 +381,10 @@ def main():
                          "the bf16 peak).  bf16 = operands rounded to bf16 (BASELINE config 5): NOT a parity mode")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="PPO cfg override, e.g. --set graph_update=True --set rng=torch --set fused_rollout=False")
-    ap.add_argument("--profile-tag", default="r4", help="prefix of the PMC / kernel-trace summaries under profiles/")
+    ap.add_argument("--profile-tag", default="r5", help="prefix of the PMC / kernel-trace summaries under profiles/")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary record (the same workload with split-bf16 GEMM operands, measured AFTER the "
+                         "timed region of the fp32 headline; single process, fp32 workloads only)")
     ap.add_argument("--shard-of", type=int, default=0, metavar="W",
                     help="single process, no collectives: run ONE rank's share of a strong-scaling workload as if the "
                          "world had W ranks (compute side of the scaling curve on a one-GPU box)")
@@ -467,24 +546,16 @@ def main():
         M = trainer.M
         if trainer.graph_update or not ev:         # eager replay of the group on the data of the last iteration
             # (also when the eager trainer took the one-call optimiser step, which the wrapper above does not see)
-            trainer._update_buffers()
-            # (env-sharded runs normalise advantages with the statistics of the GLOBAL minibatch: hand the kernel the
-            # first pair the last iteration computed)
-            adv_stats = trainer._adv_stats_all[0] if trainer.hp.adv_stats_external else None
             # rank 0 is alone here: with gradient buckets on, the gradient call itself would all-reduce - and wait for
             # peers that are already at the final barrier
             ov_replay = bool(trainer.grad_overlap)
             if ov_replay:
                 nat.set_grad_overlap(False)
-            for _ in range(12):
-                timed_grad(trainer.agent.shape, trainer.hp, trainer.agent.flat, trainer._x_g, trainer._act_g,
-                           trainer._scal_g, trainer._advp_g, M, trainer.agent.value_rms.running_mean,
-                           trainer.agent.value_rms.running_var, adv_stats, trainer.grad, trainer.diag)
-            torch.cuda.synchronize()
+            grad_us, n_timed = time_group_eager(trainer)
             if ov_replay:
                 nat.set_grad_overlap(True)
-            ev[:] = ev[2:]
-        grad_us = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3
+        else:
+            grad_us, n_timed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3, len(ev)
         macs = fwd_macs(w["obs_dim"], w["hidden"])
         flops_per_launch = 3 * 2 * macs * M                       # fwd + bwd = 3x fwd, per minibatch
         ach = flops_per_launch / grad_us / 1e6
@@ -493,11 +564,12 @@ def main():
         peak = MFMA_BF16_PEAK_TFLOPS if bf16 else MFMA_F32_PEAK_TFLOPS
         # bf16x3 issues three bf16 MFMAs per algorithmic product: the matrix pipe executes 3x the algorithmic FLOPs
         mfma_flops_factor = 3.0 if prec == "bf16x3" else 1.0
-        traffic, traffic_src, traffic_note = (None, None, "bf16 mode: no PMC pass") if bf16 else \
-            pmc_traffic(a.workload, a.profile_tag)
-        if traffic_note and not bf16:
+        # PMC / trace summaries of a non-default precision carry it in their name: r5_pmc_traffic_cfg2_bf16x3.json
+        wl_key = a.workload if prec == w.get("mlp_precision", "fp32") else f"{a.workload}_{prec}"
+        traffic, traffic_src, traffic_note = pmc_traffic(wl_key, a.profile_tag)
+        if traffic_note:
             print(f"[bench] roofline.traffic = null: {traffic_note}", file=sys.stderr)
-        prof_us, prof_src = (None, None) if bf16 else profiled_group_us(a.workload, a.profile_tag)
+        prof_us, prof_src = profiled_group_us(wl_key, a.profile_tag)
         n_mb_steps = int(agent_cfg.updates_epochs) * trainer.n_mb
         it_flops = (w["num_steps"] * trainer.N * 2 * macs) + n_mb_steps * flops_per_launch     # rollout fwd + update
         from cat_envs import native
@@ -558,8 +630,12 @@ def main():
                          "partial fold) per " + str(M) + "-sample minibatch",
                          "achieved": ach * mfma_flops_factor, "peak": peak, "unit": "TFLOP/s",
                          "frac": ach * mfma_flops_factor / peak, "algorithmic_tflops": ach,
-                         "executed_over_algorithmic_flops": mfma_flops_factor,
-                         "traffic": traffic, "avg_launch_us": grad_us, "launches_timed": len(ev),
+                         # what the matrix pipe executes per launch (padded observations, no first-layer data gradient,
+                         # 16-output head tiles), x 3 MFMAs per product in the split-bf16 mode
+                         "executed_flops": 2 * executed_macs(trainer.Dp, w["hidden"]) * M * mfma_flops_factor,
+                         "executed_over_algorithmic_flops": 2 * executed_macs(trainer.Dp, w["hidden"]) * M * mfma_flops_factor
+                                                            / flops_per_launch,
+                         "traffic": traffic, "avg_launch_us": grad_us, "launches_timed": n_timed,
                          "dominant_kernel_us_profiled": prof_us, "profiled_source": prof_src,
                          # the same FLOPs over the COMMITTED rocprofv3 duration of the group (profiler on, another box)
                          "frac_profiled": None if not prof_us else
@@ -573,6 +649,10 @@ def main():
                     "hbm_sweep": [gae_roofline(nat, 24, 1 << 20, 20), gae_roofline(nat, 48, 1 << 22, 10)],
                     "bound": "hbm", "peak_GBps": HBM_PEAK_GBPS, "bytes_per_env_step": 24},
         }
+        # (--no-cpu-baseline = the diagnostic form the A/B and profiling scripts use: no secondary record either, so that a
+        # kernel trace of that command holds the kernels of ONE precision)
+        if world == 1 and prec == "fp32" and not a.no_secondary and not a.no_cpu_baseline and a.shard_of == 0:
+            out["secondary"] = secondary_record(a, w, dev_index, max(3, a.steps // 2), max(2, a.warmup // 2))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, trainer, env, agent_cfg)
     else:
