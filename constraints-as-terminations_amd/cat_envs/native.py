@@ -191,6 +191,7 @@ _SIGNATURES = {
     "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "catppo_rlg_episode_step": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     # ---- ABI 0.5
+    "catppo_plan_log": (C.c_char_p, [_vp, C.c_int]),
     "catppo_adv_moments_keyed": (C.c_int, [_vp, _vp, C.c_int, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     # ---- ABI 0.4
     "catppo_set_grad_overlap": (C.c_int, [_vp, C.c_int]),
@@ -411,6 +412,10 @@ class Native:
         _chk(moments, torch.float64, "moments")
         self._ok(self.lib.catppo_adv_moments_parts(self.h, _p(adv_part_g), int(parts_per_mb), int(total),
                                                    int(minibatch), _p(moments), self._stream()))
+
+    def plan_log(self, enable: int = -1) -> str:
+        """ABI 0.5: start (1) / stop (0) / read (-1) the record of launch decisions of the MLP entry points"""
+        return (self.lib.catppo_plan_log(self.h, int(enable)) or b"").decode()
 
     def adv_moments_keyed(self, advantages, st, n_epochs, total, minibatch, parts_scratch, moments):
         """{sum, sum of squares, rows} of every minibatch of ALL ``n_epochs`` keyed permutations of this iteration

@@ -5,6 +5,16 @@
 
 extern "C" int catppo_version(void) { return CATPPO_VERSION; }
 
+extern "C" const char* catppo_plan_log(catppo_ctx* ctx, int enable) {
+  if (!ctx) return "";
+  if (enable > 0) {            // start recording (clears the log)
+    ctx->plan_on = true, ctx->plan_len = 0, ctx->plan[0] = 0;
+  } else if (enable == 0) {    // stop recording, keep the text
+    ctx->plan_on = false;
+  }                            // enable < 0: just read
+  return ctx->plan;
+}
+
 extern "C" int catppo_create(int device, catppo_ctx** out) {
   if (!out) return CATPPO_E_ARG;
   *out = nullptr;

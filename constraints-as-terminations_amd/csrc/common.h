@@ -37,7 +37,23 @@ struct catppo_ctx {
   static constexpr int kTicketPre = 0;     // rollout_pre: [0] launch-wide + [1..32] per workgroup group
   static constexpr int kTicketPost = 40;   // rollout_post
   char err[512] = {0};
+  // catppo_plan_log: when on, the dispatch code of the MLP entry points appends one line per launch decision (which
+  // kernel a shape gets, and why) - written AT the decision sites, so it cannot drift from what runs
+  bool plan_on = false;
+  int plan_len = 0;
+  char plan[8192] = {0};
 };
+
+inline void catppo_plan_note(catppo_ctx* ctx, const char* fmt, ...) {
+  if (!ctx || !ctx->plan_on || ctx->plan_len >= (int)sizeof(ctx->plan) - 2) return;
+  va_list ap;
+  va_start(ap, fmt);
+  const int n = vsnprintf(ctx->plan + ctx->plan_len, sizeof(ctx->plan) - ctx->plan_len - 1, fmt, ap);
+  va_end(ap);
+  if (n > 0) ctx->plan_len += n < (int)sizeof(ctx->plan) - ctx->plan_len - 1 ? n : (int)sizeof(ctx->plan) - ctx->plan_len - 2;
+  ctx->plan[ctx->plan_len++] = '\n';
+  ctx->plan[ctx->plan_len] = 0;
+}
 
 inline int catppo_fail(catppo_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {

@@ -48,6 +48,11 @@ typedef struct catppo_ctx catppo_ctx;
 
 /* ---- lifecycle ------------------------------------------------------------------- */
 int catppo_version(void);
+/* ABI 0.5: which kernels does a shape get?  enable > 0 starts recording (clears the log), 0 stops, < 0 only reads; returns
+ * the text recorded so far: one line per launch decision of catppo_policy_act* / catppo_value* /
+ * catppo_ppo_minibatch_grad* / _step_packed (kernel, grid shape, the rule that selected it), written at the decision
+ * sites themselves.  tools/explain_plan.py prints it for a (obs_dim, hidden, rows) triple. */
+const char* catppo_plan_log(catppo_ctx* ctx, int enable);
 int catppo_create(int device, catppo_ctx** out);
 void catppo_destroy(catppo_ctx* ctx);
 const char* catppo_last_error(catppo_ctx* ctx);

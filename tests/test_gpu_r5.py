@@ -291,3 +291,25 @@ def test_shape_generic_row_resident_rollout_forward_equals_the_layerwise_path(tm
         else:
             np.testing.assert_allclose(f[k], l[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(l[k]).max())), err_msg=k)
     assert np.abs(f["ref_act"]).max() > 0 and np.isfinite(f["ref_ragged_lp"]).all()
+
+
+# ------------------------------------------------------------------------------------------ which kernels does a shape get
+def test_plan_log_names_the_kernels_a_shape_gets():
+    """catppo_plan_log (ABI 0.5): the dispatch code writes one line per launch decision at the decision
+    site; tools/explain_plan.py prints it.  The benchmark shape takes rows_fwd_kernel + fwd_head_kernel, the reference's own
+    network (cleanrl/ppo.py:78-96) rows_fwd_wide_kernel in both phases, a 2048-row shard the layer-wise path."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import explain_plan as E
+    cfg2 = E.explain(48, 12, (256, 256, 256), 4096, 16384)
+    assert "rows_fwd_kernel<32> + heads" in cfg2 and "rows_fwd_kernel<64>" in cfg2 and "fwd_head_kernel<256, prec 0>" in cfg2
+    assert cfg2.count("gemm_pair_kernel, ONE launch") == 2 and "dw_fold_kernel" in cfg2 and "clip_adam_dev_kernel" in cfg2
+    ref = E.explain(45, 12, (512, 256, 128), 4096, 16384)
+    assert "rows_fwd_wide_kernel<32> + heads" in ref and "rows_fwd_wide_kernel<64>" in ref and "in 2 chunk(s)" in ref
+    assert "fwd_head_kernel<128, prec 0>" in ref
+    shard = E.explain(45, 12, (512, 256, 128), 2048, 2048)
+    assert "layer-wise" in shard and "head_loss_kernel" in shard and "64x64 weight-gradient tiles" in shard
+    from cat_envs import native
+    nat = native.get(torch.device("cuda", 0))
+    assert nat.plan_log(-1) == nat.plan_log(-1) and "clip + Adam" in nat.plan_log(-1)      # reading does not clear
+    assert nat.plan_log(1) == ""                                                             # starting does
+    nat.plan_log(0)
