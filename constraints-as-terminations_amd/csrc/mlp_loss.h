@@ -350,6 +350,9 @@ __device__ unsigned long long* g_fhtl;    // [2 nets][1024 workgroups][8 stamps]
 #define FH_TL(i) do { } while (0)
 #endif
 
+#ifndef FWD_HEAD_MFMA16
+#define FWD_HEAD_MFMA16 1          // 0: steps A and C on v_mfma_f32_32x32x2_f32 with the 16 head outputs padded to 32 (rounds 2-4)
+#endif
 template <int HL>
 constexpr size_t fwd_head_lds_floats() { return (size_t)64 * (HL + gemm::kLdsTilePad) + 64 * 16 + 64 * 16 + 64 * 8 + 4; }
 
@@ -407,10 +410,21 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   // Everything the epilogue reads from global memory is requested here, ahead of the main loop: the head weights in
   // the operand layouts of steps A and B (rows past KH zero) and the gathered scalars of the row this thread will
   // work on (row math: four threads per row, thread part pp owns the action dims pp, pp+4, pp+8, pp+12).
+#if FWD_HEAD_MFMA16
+  // steps A and C on v_mfma_f32_16x16x4_f32 (round 5): 16 head outputs = ONE 16-wide tile, no zero-padded half as in the
+  // 32x32x2 form (64 MFMAs x 32 cycles per wave and step instead of 64 x 64; profiles/r5_fwd_head_timeline.txt).
+  // lane = (c16 = lane % 16: head output / column inside a tile, g4 = lane / 16: one of the 4 k of an instruction)
+  const int c16 = lane & 15, g4 = lane >> 4;
+  float4 bw[KQ / 16];          // step A: Wh[c16][q KQ + 16 blk + 4 g4 + s], MFMA (blk, s) contracts k = 16 blk + 4 g + s over g
+#pragma unroll
+  for (int kb = 0; kb < KQ / 16; ++kb)
+    bw[kb] = c16 < KH ? *reinterpret_cast<const float4*>(Wh + c16 * HL + q * KQ + 16 * kb + 4 * g4) : zero4;
+#else
   float4 bw[KQ / 8];
 #pragma unroll
   for (int kb = 0; kb < KQ / 8; ++kb)
     bw[kb] = l31 < KH ? *reinterpret_cast<const float4*>(Wh + l31 * HL + q * KQ + 8 * kb + 4 * h) : zero4;
+#endif
   float bwB[TNB][2][4];
 #pragma unroll
   for (int tn = 0; tn < TNB; ++tn)
@@ -444,6 +458,42 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   //         both operands (gemm_body's K-contiguous fragments)
   {
     __syncthreads();                                     // H tile complete
+#if FWD_HEAD_MFMA16
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    f32x4 c[4];                                          // rows 16 t + 4 g4 + reg, head output c16
+#pragma unroll
+    for (int t = 0; t < 4; ++t) c[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KQ / 16; ++kb) {
+      float4 a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const float4*>(Hs + (16 * t + c16) * LD + q * KQ + 16 * kb + 4 * g4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, bw[kb].x, c[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, bw[kb].y, c[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, bw[kb].z, c[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, bw[kb].w, c[t], 0, 0, 0);
+    }
+    // the four contraction quarters in fixed order, two rounds: sMu = q0 + q1, sG = q2 + q3 (sG is free until the row
+    // math writes it); the row math adds the two halves
+    for (int w = 0; w < 2; ++w) {
+      if ((q & 1) == w) {
+        float* half = (q >> 1) ? sG : sMu;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d = half + (16 * t + 4 * g4 + r) * 16 + c16;
+            *d = (w == 0 ? 0.0f : *d) + c[t][r];
+          }
+      }
+      __syncthreads();
+    }
+  }
+#else
     f32x16 c0, c1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) c0[r] = 0.0f, c1[r] = 0.0f;
@@ -477,6 +527,8 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
       __syncthreads();
     }
   }
+
+#endif
 
   FH_TL(2);
   const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
@@ -566,6 +618,32 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   // ---- C: head weight gradient of the tile, dWh[k][c] = sum_r G[r][k] H[r][c]; wave q owns TNC column tiles
   const int prow = net == 1 ? tile : RB + tile;
   {
+#if FWD_HEAD_MFMA16
+    // D tile = 16 head outputs x 16 columns; contraction over the tile's 64 rows, 4 per instruction (row 4 step + g4)
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    constexpr int TC = HL / 64;                          // 16-column tiles per wave (a wave owns HL / 4 columns)
+    f32x4 cc[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) cc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int col0 = q * (HL / 4);
+#pragma unroll 4
+    for (int s = 0; s < BM / 4; ++s) {
+      const int r = 4 * s + g4;
+      const float a = sG[r * 16 + c16];
+#pragma unroll
+      for (int t = 0; t < TC; ++t)
+        cc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Hs[r * LD + col0 + 16 * t + c16], cc[t], 0, 0, 0);
+    }
+    float* pw = g.part_w + (int64_t)prow * (A + 1) * HL + (net == 1 ? 0 : (int64_t)A * HL);   // rows 0..A-1 = dW4a, row A = dW4c
+#pragma unroll
+    for (int t = 0; t < TC; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {                      // accumulator row 4 g4 + r = head output
+        const int k = 4 * g4 + r;
+        if (k < KH) pw[k * HL + col0 + 16 * t + c16] = cc[t][r];
+      }
+  }
+#else
     f32x16 cc[TNC];
 #pragma unroll
     for (int t = 0; t < TNC; ++t)
@@ -589,6 +667,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
         if (k < KH) pw[k * HL + col0 + 32 * t + l31] = cc[t][r];
       }
   }
+#endif
   __syncthreads();                                       // every read of H is done: step B overwrites it
   FH_TL(4);
 
