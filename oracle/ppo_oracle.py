@@ -276,9 +276,17 @@ def ppo_minibatch_loss(agent: AgentOracle, mb_obs, mb_actions, mb_logprobs, mb_a
         v_loss = 0.5 * ((newvalue - mb_returns_n) ** 2).mean()
     ent = entropy.mean()
     loss = pg_loss - cfg["ent_coef"] * ent + v_loss * cfg["vf_coef"]
+    with torch.no_grad():
+        # distance of the closest sample to a point where the GRADIENT of the clipped objectives is discontinuous
+        # (|ratio - 1| = clip for the surrogate, |newvalue - old value| = clip for the clipped value loss): a sample
+        # closer to it than the rounding noise between two implementations (~1e-6) may take the other branch there, and
+        # from that optimiser step on the two parameter trajectories differ by more than rounding.  Test diagnostics only.
+        margin = ((ratio - 1.0).abs() - cfg["clip_coef"]).abs().min()
+        if cfg["clip_vloss"]:
+            margin = torch.minimum(margin, ((newvalue - mb_values_n).abs() - cfg["clip_coef"]).abs().min())
     return loss, {"pg_loss": pg_loss.detach(), "v_loss": v_loss.detach(), "entropy": ent.detach(),
                   "loss": loss.detach(), "approx_kl": approx_kl, "old_approx_kl": old_approx_kl,
-                  "clipfrac": clipfrac}
+                  "clipfrac": clipfrac, "clip_boundary_margin": margin}
 
 
 class PPOOracle:
@@ -375,6 +383,9 @@ class PPOOracle:
                                               b_returns[mb], b_values[mb], c)
                 for k in sums:
                     sums[k] = sums[k] + st[k]
+                # closest approach of any sample to a clip boundary over the optimiser steps of this oracle (diagnostic)
+                self.clip_boundary_margin = min(getattr(self, "clip_boundary_margin", float("inf")),
+                                                float(st["clip_boundary_margin"]))
                 self.opt.zero_grad()
                 loss.backward()
                 torch.nn.utils.clip_grad_norm_(self.params, c["max_grad_norm"])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # final validation + profile refresh: everything that gets committed under profiles/ is produced here
 set -u
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
@@ -15,7 +15,13 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 echo "== profile passes first (the bench line then finds a PMC summary stamped with this tree) ($(( $(date +%s) - T0 )) s)"
 bash tools/profile_bench.sh cfg2 $TAG > "$OUT/final_profile.log" 2>&1
 python tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq1_cfg2.csv" "$OUT/${TAG}_pmc_sq2_cfg2.csv" > "$OUT/${TAG}_pmc_sq_summary_cfg2.json" 2>/dev/null
-mkdir -p profiles && cp "$OUT/${TAG}_pmc_traffic_cfg2.json" "$OUT/${TAG}_bench_cfg2_kernel_stats.csv" profiles/ 2>/dev/null
+# the reduced-precision modes: kernel trace + FETCH / WRITE passes (round 5: they had `traffic: null`)
+SQ_PASSES=0 BENCH_ARGS="--mlp-precision bf16x3" bash tools/profile_bench.sh cfg2 $TAG _bf16x3 >> "$OUT/final_profile.log" 2>&1
+SQ_PASSES=0 bash tools/profile_bench.sh cfg5 $TAG >> "$OUT/final_profile.log" 2>&1
+mkdir -p profiles && cp "$OUT/${TAG}_pmc_traffic_cfg2.json" "$OUT/${TAG}_bench_cfg2_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg2_bf16x3.json" \
+   "$OUT/${TAG}_bench_cfg2_bf16x3_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg5.json" "$OUT/${TAG}_bench_cfg5_kernel_stats.csv" profiles/ 2>/dev/null
+bash tools/gpu_trace_one.sh reference $TAG > /dev/null 2>&1
+bash tools/gpu_trace_one.sh cfg3_shard $TAG > /dev/null 2>&1
 echo "== bench lines ($(( $(date +%s) - T0 )) s)"
 timeout 400 python bench.py 2> "$OUT/${TAG}_bench_cfg2.err" | tail -1 > "$OUT/${TAG}_bench_cfg2.json"
 B="timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
@@ -41,7 +47,9 @@ out=sys.argv[1]; TAG=sys.argv[2]
 def show(tag,line):
     try:
         d=json.loads(line)
-        print(tag, round(d["value"]/1e6,3),"M/s ms",round(d["ms_per_step"],2),"grp_us",round(d["roofline"]["avg_launch_us"],1),"frac",round(d["roofline"]["frac"],3),"traffic",d["roofline"]["traffic"],{k:round(v,2) for k,v in d["phases_device_ms"].items() if k!="iterations"})
+        print(tag, round(d["value"]/1e6,3),"M/s ms",round(d["ms_per_step"],2),"grp_us",round(d["roofline"]["avg_launch_us"],1),"frac",round(d["roofline"]["frac"],3),"frac_profiled",d["roofline"].get("frac_profiled"),"traffic",d["roofline"]["traffic"],{k:round(v,2) for k,v in d["phases_device_ms"].items() if k!="iterations"})
+        if d.get("secondary"):
+            s2=d["secondary"]; print("   secondary", s2["dtype"][:7], round(s2["value"]/1e6,3),"M/s ms",round(s2["ms_per_step"],2),"grp_us",round(s2["roofline"]["avg_launch_us"],1),"frac",round(s2["roofline"]["frac"],3),"traffic",s2["roofline"]["traffic"])
     except Exception as e: print(tag,"FAILED",e)
 for f in tuple(TAG + x for x in ("_bench_cfg2.json","_bench_reference.json","_bench_cfg2_bf16x3.json","_bench_cfg2_forced_dist_world1.json")):
     show(f, open(os.path.join(out,f)).read().strip().splitlines()[-1])

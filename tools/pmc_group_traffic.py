@@ -12,7 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel", "rows_fwd_kernel", "dw_fold_kernel")
+GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel", "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel")
 
 
 def per_launch(path):
@@ -23,7 +23,7 @@ def per_launch(path):
         if not any(k in r["kernel"] for k in GROUP):
             continue
         s, calls = float(r["sum"]), int(r["calls"])
-        if "<64, 64, true, true, 0, 64" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"]:
+        if "<64, 64, true, true, 0, 64" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"] or "rows_fwd_wide_kernel<32" in r["kernel"]:
             continue                    # 64-wide contraction slabs: the rollout's policy GEMMs only (<= 4096 rows)
         if "<64, 64, true, true, 0" in r["kernel"]:
             s = s / calls * n_mb        # 64x64 forward launches also serve the rollout: one (K=Dp layer) per minibatch
