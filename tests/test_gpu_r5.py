@@ -313,3 +313,21 @@ def test_plan_log_names_the_kernels_a_shape_gets():
     assert nat.plan_log(-1) == nat.plan_log(-1) and "clip + Adam" in nat.plan_log(-1)      # reading does not clear
     assert nat.plan_log(1) == ""                                                             # starting does
     nat.plan_log(0)
+
+
+def test_weight_gradient_on_64x64_tiles_when_128x128_tiles_underfill_the_chip_is_bit_identical(tmp_path):
+    """launch_dw_dx_pair (round 5): the reference's last hidden layer (256 -> 128: two 128x128 weight-gradient tiles x 2
+    networks x 32 splits = 128 long workgroups on 256 CUs) takes 64x64 tiles; same splits and contraction order per
+    element, so the flat gradient must be BIT-identical to the 128x128 tiling (CATPPO_DW_FILL=0)."""
+    import test_gpu_kernels as TK
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"fill{flag}.npz")
+        code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=45, A=12, hidden=(512, 256, 128), Bsz=16384, M=16384, prec=0, out=out)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CATPPO_DW_FILL=flag), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    assert np.abs(outs[1]["grad"]).max() > 0
+    np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
+    np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
