@@ -540,7 +540,7 @@ def main():
         barrier()
         trainer.graph_update = g_was
         if ov_was:
-            trainer.grad_overlap = nat.set_grad_overlap(True)
+            trainer.grad_overlap = nat.set_grad_overlap(getattr(trainer, '_grad_overlap_mode', True))
 
     if rank == 0:
         M = trainer.M
@@ -553,7 +553,7 @@ def main():
                 nat.set_grad_overlap(False)
             grad_us, n_timed = time_group_eager(trainer)
             if ov_replay:
-                nat.set_grad_overlap(True)
+                nat.set_grad_overlap(getattr(trainer, '_grad_overlap_mode', True))
         else:
             grad_us, n_timed = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3, len(ev)
         macs = fwd_macs(w["obs_dim"], w["hidden"])

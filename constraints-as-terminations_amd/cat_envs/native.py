@@ -736,7 +736,8 @@ class Native:
     def set_grad_overlap(self, on: bool) -> bool:
         """gradient all-reduce in per-layer buckets on the library's side stream, under the backward launches
         (ABI 0.4); returns whether the next ``ppo_minibatch_grad*`` call will reduce its own buckets"""
-        self._ok(self.lib.catppo_set_grad_overlap(self.h, int(bool(on))))
+        mode = 2 if on in (2, "tail") else int(bool(on))      # 2 / "tail": ABI 0.5, no extra launch
+        self._ok(self.lib.catppo_set_grad_overlap(self.h, mode))
         return bool(self.lib.catppo_grad_overlap_active(self.h))
 
     @property

@@ -480,12 +480,15 @@ class PPOTrainer:
         go = getattr(c, "grad_overlap", None)
         env_go = os.environ.get("CATPPO_GRAD_OVERLAP")
         if env_go is not None:
-            go = env_go == "1"
+            go = {"1": True, "2": "tail", "tail": "tail"}.get(env_go, False)
         if go is None:
             go = False
+        # (round 5: "tail" / CATPPO_GRAD_OVERLAP=2 = the no-extra-launch form, catppo_set_grad_overlap(ctx, 2): measured
+        # in profiles/r5_grad_overlap_tail_world1.txt)
         self.grad_overlap = False
         if parallel.active() and parallel.native_comm_active():
-            self.grad_overlap = self.nat.set_grad_overlap(bool(go))
+            self.grad_overlap = self.nat.set_grad_overlap(go)
+        self._grad_overlap_mode = go
         # single process: an optimiser step is ONE library call (catppo_ppo_minibatch_step_packed) whose fold launches
         # emit the squared gradient norm of the clip - the launch that re-read the gradient for it is gone.  Not with
         # exchange points on (the gradient all-reduce sits between fold and clip) nor with the side-stream experiment.

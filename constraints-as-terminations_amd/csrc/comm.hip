@@ -201,10 +201,10 @@ int catppo_internal_allreduce_ranges(catppo_ctx* ctx, float* base, const int64_t
 
 extern "C" int catppo_set_grad_overlap(catppo_ctx* ctx, int on) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  CATPPO_CHECK_ARG(ctx, on == 0 || on == 1);
+  CATPPO_CHECK_ARG(ctx, on == 0 || on == 1 || on == 2);
   if (on && ctx->use_side)
     return catppo_fail(ctx, CATPPO_E_ARG, "catppo_set_grad_overlap: the side stream is taken by CATPPO_SIDE_STREAM=1");
-  ctx->grad_overlap = on != 0;
+  ctx->grad_overlap = on;
   return CATPPO_OK;
 }
 

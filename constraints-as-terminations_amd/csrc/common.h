@@ -30,7 +30,9 @@ struct catppo_ctx {
   int comm_rank = 0, comm_world = 0;
   // catppo_set_grad_overlap: the gradient all-reduce of an optimiser step runs per layer bucket on the side stream,
   // under the backward launches of the layers below (effective only while a communicator exists)
-  bool grad_overlap = false;
+  // 0 off | 1 per-layer buckets (round 4: extra fold launches) | 2 "tail" (round 5: no extra launch - everything but the
+  // first layer is reduced on the side stream under the final fold launch)
+  int grad_overlap = 0;
   // device-side completion tickets of the "last workgroup folds" kernels (zero between launches)
   unsigned int* tickets = nullptr;   // [kTickets]
   static constexpr int kTickets = 64;

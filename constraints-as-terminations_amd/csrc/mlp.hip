@@ -654,8 +654,12 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const bool fork = ctx->use_side;
   // catppo_set_grad_overlap + a communicator: fold and all-reduce the gradient in per-layer buckets on the side stream
   // while the backward launches of the layers below run on `s` (see the end of the layer loop)
-  const bool overlap = !fork && ctx->grad_overlap && ctx->comm != nullptr;
-  if (ne != nullptr && (fork || overlap))
+  const bool overlap = !fork && ctx->grad_overlap == 1 && ctx->comm != nullptr;
+  // round 5, "tail" form: no extra launch; the ranges that are final after dw_fold_kernel travel on the side stream under
+  // the final fold launch, the first layer's own ranges behind it on `s`
+  const bool tail = !fork && ctx->grad_overlap == 2 && ctx->comm != nullptr;
+  bool tail_forked = false;
+  if (ne != nullptr && (fork || overlap || tail))
     return catppo_fail(ctx, CATPPO_E_ARG, "%s: the one-call optimiser step cannot run with the side-stream weight "
                        "gradients or the gradient buckets (something reduces the gradient between fold and clip)", __func__);
   if (ne != nullptr) ne->n_slots = 0;
@@ -740,6 +744,18 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
                        "layers / heads: dw_fold_kernel, %d + %d workgroups", out, in, splits, per, segs.n, n_gemm, kFoldX * segs.n);
       if (ne) ne->n_slots += kFoldX * segs.n;
       segs.n = 0;        // folded; what is added below (this layer's own partials) goes to the final fold launch
+      if (tail) {
+        // every range of the flat gradient except the first layer's (W0 | b0 of both networks) is final now
+        CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[0], s));
+        CATPPO_HIP_OK(hipStreamWaitEvent(ctx->side, ctx->ev_fork[0], 0));
+        int64_t off[3], cnt[3];
+        off[0] = L.off_logstd, cnt[0] = L.off_w[0][0] - L.off_logstd;
+        off[1] = L.off_w[0][1], cnt[1] = L.off_w[1][0] - L.off_w[0][1];
+        off[2] = L.off_w[1][1], cnt[2] = L.n_flat - L.off_w[1][1];
+        if (int rc = catppo_internal_allreduce_ranges(ctx, grad, off, cnt, 3, ctx->side)) return rc;
+        CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, ctx->side));
+        tail_forked = true;
+      }
     } else if (!pair) {
       launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
       catppo_plan_note(ctx, "layer %d weight gradient (%d x %d, %d splits of %d rows): gemm_f32_kernel, split-K partials "
@@ -834,6 +850,16 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
                    ne ? " + squared-norm slots and Adam step advance (one-call optimiser step)" : "");
   CATPPO_CHECK_LAUNCH(ctx);
   if (ne) ne->n_slots += 256 * segs.n;
+  if (tail) {
+    if (tail_forked) {      // join first: two operations on one communicator are never in flight on two streams at once
+      CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));
+      int64_t off[2] = {L.off_w[0][0], L.off_w[1][0]}, cnt[2] = {L.off_w[0][1] - L.off_w[0][0], L.off_w[1][1] - L.off_w[1][0]};
+      if (int rc = catppo_internal_allreduce_ranges(ctx, grad, off, cnt, 2, s)) return rc;
+    } else {                // shapes whose first-layer weight gradient does not share its launch with the fold: one all-reduce
+      int64_t off[1] = {0}, cnt[1] = {L.n_flat};
+      if (int rc = catppo_internal_allreduce_ranges(ctx, grad, off, cnt, 1, s)) return rc;
+    }
+  }
   if (fork) {
     CATPPO_HIP_OK(hipEventRecord(ctx->ev_join, side));
     CATPPO_HIP_OK(hipStreamWaitEvent(s, ctx->ev_join, 0));

@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kFT) void fused_fwd_kernel(const FusedFwdArgs a) {
   float* ring = act1 + kFR * a.ld1;                       // [3][256][kFWS]
   const int net = a.net0 + blockIdx.y;
   const int64_t r0 = (int64_t)blockIdx.x * kFR;
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   FF_TL(0);

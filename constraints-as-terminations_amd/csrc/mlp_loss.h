@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   constexpr int BM = 64, LD = HL + gemm::kLdsTilePad;
   constexpr int KQ = HL / 4;            // contraction share of a wave in step A
   constexpr int TNB = HL / 64;          // 32-column tiles per wave in step B (waves 2 x 2)
-  constexpr int TNC = HL / 128;         // 32-column tiles per wave in step C (waves 1 x 4)
+  [[maybe_unused]] constexpr int TNC = HL / 128;         // 32-column tiles per wave in step C (waves 1 x 4)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Hs = smem;                     // [64][LD]   activated tile, later dZ
   float* sG = Hs + BM * LD;             // [64][16]   d loss / d head output k of row r (zero beyond the real outputs)

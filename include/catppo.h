@@ -627,6 +627,10 @@ int catppo_allgather(catppo_ctx* ctx, const void* send, void* recv, int64_t byte
  * GLOBAL sum when the next operation on `stream` (catppo_clip_adam*) reads it and the caller must NOT all-reduce it
  * again.  Sums per element are those of the single fold launch (bit-identical on a world of one); the whole sequence
  * is capturable.  catppo_grad_overlap_active: 1 when the next gradient call will reduce its own buckets. */
+/* ABI 0.5: on == 2 selects the "tail" form - NO extra launch: once the launch that folds every layer above the first is
+ * enqueued (dw_fold_kernel), those ranges of the flat gradient are all-reduced on the side stream under the final fold
+ * launch of the first layer's own partials, which are reduced on the caller's stream behind a join.  Measured on a world of
+ * one: see profiles/r5_grad_overlap_tail_world1.txt. */
 int catppo_set_grad_overlap(catppo_ctx* ctx, int on);
 int catppo_grad_overlap_active(catppo_ctx* ctx);
 

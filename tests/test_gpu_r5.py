@@ -331,3 +331,21 @@ def test_weight_gradient_on_64x64_tiles_when_128x128_tiles_underfill_the_chip_is
     assert np.abs(outs[1]["grad"]).max() > 0
     np.testing.assert_array_equal(outs[0]["grad"], outs[1]["grad"])
     np.testing.assert_array_equal(outs[0]["diag"], outs[1]["diag"])
+
+
+def test_gradient_tail_reduced_under_the_final_fold_launch_world_of_one():
+    """catppo_set_grad_overlap(ctx, 2) (ABI 0.5): no extra launch - the ranges of the flat gradient that
+    are final after dw_fold_kernel are all-reduced on the side stream under the final fold launch, the first layer's behind
+    a join; eager and captured, world of one: parameters, Adam state, diagnostics BIT-identical to one all-reduce.  The
+    240-wide case takes the shape whose first layer does not share its launch with the fold (one all-reduce inside the
+    call)."""
+    import test_gpu_r4 as r4
+    code = (r4._OVERLAP_CODE.replace('dict(grad_overlap=True, graph_update=False)', 'dict(grad_overlap="tail", graph_update=False)')
+            .replace('dict(grad_overlap=True, graph_update=True)', 'dict(grad_overlap="tail", graph_update=True)')
+            .replace('tr.grad_overlap == over["grad_overlap"] == tr.nat.grad_overlap_active',
+                     'tr.grad_overlap == bool(over["grad_overlap"]) == tr.nat.grad_overlap_active')
+            .replace("OVERLAP-OK", "TAIL-OK"))
+    assert '"tail"' in code and "TAIL-OK" in code
+    for obs in (48, 235):
+        r = r4._run_code(code.replace("obs_dim=48", f"obs_dim={obs}"))
+        assert r.returncode == 0 and "TAIL-OK" in r.stdout, (obs, r.stdout[-2000:] + r.stderr[-4000:])
