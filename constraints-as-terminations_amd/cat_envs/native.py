@@ -173,6 +173,8 @@ _SIGNATURES = {
     "catppo_rollout_step_sizeof": (C.c_uint64, []),
     "catppo_rollout_pre": (C.c_int, [_vp, C.POINTER(RolloutStep), _vp]),
     "catppo_rollout_post": (C.c_int, [_vp, C.POINTER(RolloutStep), _vp]),
+    "catppo_rollout_defer_tail": (C.c_int, [_vp, C.c_int, _vp]),
+    "catppo_rollout_flush": (C.c_int, [_vp, _vp]),
     "catppo_graph_begin": (C.c_int, [_vp, _vp]),
     "catppo_graph_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "catppo_graph_launch": (C.c_int, [_vp, C.c_int, _vp]),
@@ -689,6 +691,14 @@ class Native:
 
     def rollout_post(self, step: RolloutStep):
         self._ok(self.lib.catppo_rollout_post(self.h, C.byref(step), self._stream()))
+
+    def rollout_defer_tail(self, on: bool):
+        """ABI 0.5: while on, catppo_rollout_post leaves its one-workgroup tail (running maxima / normaliser state /
+        episode log) to the next catppo_rollout_pre launch; ``False`` switches it off AND runs a tail still pending"""
+        self._ok(self.lib.catppo_rollout_defer_tail(self.h, int(bool(on)), self._stream()))
+
+    def rollout_flush(self):
+        self._ok(self.lib.catppo_rollout_flush(self.h, self._stream()))
 
     # ------------------------------------------------------------------ hipGraphs
     def graph_begin(self):

@@ -445,6 +445,11 @@ class PPOTrainer:
         if bool(getattr(c, "fused_rollout", True)) and hasattr(env_u, "step_into") and \
                 getattr(env_u, "can_step_into", lambda: False)() and os.environ.get("CATPPO_FUSED_ROLLOUT", "1") != "0":
             self.sink = RolloutSink(self)
+        dt = getattr(c, "defer_rollout_tail", None)
+        if os.environ.get("CATPPO_ROLLOUT_DEFER_TAIL") is not None:
+            dt = os.environ["CATPPO_ROLLOUT_DEFER_TAIL"] != "0"
+        #: catppo_rollout_defer_tail around the env steps of a rollout (fused path only)
+        self.defer_tail = True if dt is None else bool(dt)
         # hipGraph replay of the update phase
         g = getattr(c, "graph_update", None)
         env_g = os.environ.get("CATPPO_GRAPH_UPDATE")
@@ -546,50 +551,60 @@ class PPOTrainer:
         vdt = native.F16 if self.plane_dtype == torch.float16 else native.F32
         act_rows = self._act_rows
         use_rng = eps_fn is None and self.rng != "torch"
-        for step in range(T):
-            self.global_step += N * self.world
-            if use_rng:                                          # Philox noise inside the head kernel
-                rc = lib.catppo_policy_act_rng(
-                    h, shp, p_flat, p_obs + step * s_obs, N, p_state, step,
-                    self.noise_rec[step].data_ptr() if self.record_noise else None, p_act + step * s_act,
-                    p_lp + step * s_lp, p_val + step * s_val, vdt, nat._stream())
-            else:
-                eps = self.noise[step] if eps_fn is None else eps_fn(step)
-                rc = lib.catppo_policy_act_ex(h, shp, p_flat, p_obs + step * s_obs, N, eps.data_ptr(), None,
-                                              p_act + step * s_act, p_lp + step * s_lp, p_val + step * s_val, vdt,
-                                              nat._stream())
-            if rc:
-                nat._ok(rc)
-            if self.sink is not None:
-                self.sink.step = step
-                next_obs, reward, next_done, timeouts, info = env_u.step_into(act_rows[step], self.sink)
-            else:
-                next_obs, reward, next_done, timeouts, info = self.envs.step(self.actions[step])
-                if (reward.dtype == torch.float32 and next_done.dtype == torch.float32 and timeouts.dtype == torch.bool
-                        and reward.is_contiguous() and next_done.is_contiguous() and timeouts.is_contiguous()):
-                    nat.rollout_store_ex(reward, next_done, timeouts, self.rewards[step], self.dones[step + 1],
-                                         self.true_dones[step + 1])
-                else:                                            # foreign env: dtype conversions in the copies
-                    self.rewards[step].copy_(reward)
-                    self.dones[step + 1].copy_(next_done)
-                    self.true_dones[step + 1].copy_(timeouts)
-                a.obs_rms.normalize_into(self._rows(next_obs["policy"]), self.obs[step + 1])
-            if "episode" in info:
-                ep_infos.append(info["episode"])
-            elif "log" in info:
-                packed = info.get("log_packed")
-                if packed is None:
-                    ep_infos.append(info["log"])
-                else:                                 # (keys, device tensor) + the host-side scalars of the log
-                    host = info.get("log_host")
-                    extra = dict(host) if host is not None else \
-                        {k: v for k, v in info["log"].items() if not isinstance(v, torch.Tensor)}
-                    ep_infos.append((packed[0], packed[1], extra))
-            info["true_dones"] = timeouts
-            if "time_outs" in info:
-                if info["time_outs"].any():
-                    print("time outs", info["time_outs"].sum())
-                    exit(0)
+        # the one-workgroup tail of the fused env step (running maxima / normaliser state / episode log: read by the NEXT
+        # env step and by the logging below, not by the policy forward) rides in the next step's first launch instead of
+        # standing between catppo_rollout_post and the forward (catppo_rollout_defer_tail; CATPPO_ROLLOUT_DEFER_TAIL=0: A/B)
+        defer = self.sink is not None and self.defer_tail
+        if defer:
+            nat.rollout_defer_tail(True)
+        try:
+            for step in range(T):
+                self.global_step += N * self.world
+                if use_rng:                                          # Philox noise inside the head kernel
+                    rc = lib.catppo_policy_act_rng(
+                        h, shp, p_flat, p_obs + step * s_obs, N, p_state, step,
+                        self.noise_rec[step].data_ptr() if self.record_noise else None, p_act + step * s_act,
+                        p_lp + step * s_lp, p_val + step * s_val, vdt, nat._stream())
+                else:
+                    eps = self.noise[step] if eps_fn is None else eps_fn(step)
+                    rc = lib.catppo_policy_act_ex(h, shp, p_flat, p_obs + step * s_obs, N, eps.data_ptr(), None,
+                                                  p_act + step * s_act, p_lp + step * s_lp, p_val + step * s_val, vdt,
+                                                  nat._stream())
+                if rc:
+                    nat._ok(rc)
+                if self.sink is not None:
+                    self.sink.step = step
+                    next_obs, reward, next_done, timeouts, info = env_u.step_into(act_rows[step], self.sink)
+                else:
+                    next_obs, reward, next_done, timeouts, info = self.envs.step(self.actions[step])
+                    if (reward.dtype == torch.float32 and next_done.dtype == torch.float32 and timeouts.dtype == torch.bool
+                            and reward.is_contiguous() and next_done.is_contiguous() and timeouts.is_contiguous()):
+                        nat.rollout_store_ex(reward, next_done, timeouts, self.rewards[step], self.dones[step + 1],
+                                             self.true_dones[step + 1])
+                    else:                                            # foreign env: dtype conversions in the copies
+                        self.rewards[step].copy_(reward)
+                        self.dones[step + 1].copy_(next_done)
+                        self.true_dones[step + 1].copy_(timeouts)
+                    a.obs_rms.normalize_into(self._rows(next_obs["policy"]), self.obs[step + 1])
+                if "episode" in info:
+                    ep_infos.append(info["episode"])
+                elif "log" in info:
+                    packed = info.get("log_packed")
+                    if packed is None:
+                        ep_infos.append(info["log"])
+                    else:                                 # (keys, device tensor) + the host-side scalars of the log
+                        host = info.get("log_host")
+                        extra = dict(host) if host is not None else \
+                            {k: v for k, v in info["log"].items() if not isinstance(v, torch.Tensor)}
+                        ep_infos.append((packed[0], packed[1], extra))
+                info["true_dones"] = timeouts
+                if "time_outs" in info:
+                    if info["time_outs"].any():
+                        print("time outs", info["time_outs"].sum())
+                        exit(0)
+        finally:
+            if defer:
+                nat.rollout_defer_tail(False)          # = flush: everything the steps wrote is current from here on
         return ep_infos
 
     # ------------------------------------------------------------------ GAE + normalisers (:251-288)

@@ -63,6 +63,7 @@ extern "C" void catppo_destroy(catppo_ctx* ctx) {
   for (auto& g : ctx->graphs)
     if (g) (void)hipGraphExecDestroy(g);
   if (ctx->tickets) (void)hipFree(ctx->tickets);
+  if (ctx->post_rpart) (void)hipFree(ctx->post_rpart);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->side) (void)hipStreamDestroy(ctx->side);
   for (auto& e : ctx->ev_fork)

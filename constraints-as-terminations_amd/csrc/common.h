@@ -38,6 +38,16 @@ struct catppo_ctx {
   static constexpr int kTickets = 64;
   static constexpr int kTicketPre = 0;     // rollout_pre: [0] launch-wide + [1..32] per workgroup group
   static constexpr int kTicketPost = 40;   // rollout_post
+  // catppo_rollout_defer_tail (rollout.hip): the one-workgroup tail of rollout_post (publish the new running maxima /
+  // normaliser state, fold the reset statistics) rides in the NEXT rollout_pre launch instead of standing at the end of
+  // the post launch, behind a "last workgroup arrives" hand-shake, in front of the policy forward
+  bool rollout_defer = false;
+  bool post_tail_pending = false;
+  int post_tail_nblk = 0;                               // workgroups of the post launch whose tail is pending
+  void* post_tail_stream = nullptr;
+  alignas(16) unsigned char post_tail_args[512] = {0};  // that launch's PostArgs
+  double* post_rpart = nullptr;                         // its reset-statistics rows: owned (the workspace is reused by
+  uint64_t post_rpart_bytes = 0;                        // whatever runs between the two launches), grown on demand
   char err[512] = {0};
   // catppo_plan_log: when on, the dispatch code of the MLP entry points appends one line per launch decision (which
   // kernel a shape gets, and why) - written AT the decision sites, so it cannot drift from what runs

@@ -82,6 +82,8 @@ struct PreArgs {
   float4* sim_dst;
   int sim_row_q4;
   int tree;                 // 1: fold the partial rows inside this launch (rounds 2-3); 0: rollout_fold_kernel does it
+  int nblk;                 // workgroups that walk tiles (the grid holds one more when a deferred post tail rides along)
+  int tail_nblk;            // workgroups of the post launch whose tail rides along (its partial rows)
 };
 constexpr int kFoldGroup = 32;    // workgroups per first-level fold
 constexpr int kMaxPreBlocks = 1024;
@@ -151,8 +153,148 @@ __device__ __forceinline__ void block_fold(const T* __restrict__ partial, int nr
   }
 }
 
-__global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable tab, const PreArgs a) {
+struct TermMetaS {
+  int32_t off[kMaxTerms + 1];
+  float dp[kMaxTerms];
+};
+
+struct PostArgs {
+  int64_t N;
+  int A, D, K, n_terms;
+  const float* cstr;
+  float min_p, tau, one_minus_tau;
+  int first_call;
+  float* rm;
+  float* reward;
+  const uint8_t* reset;
+  const uint8_t* time_outs;
+  float* cstr_prob;
+  float* dones;
+  float* ep_viol;
+  float* ep_prob;
+  float* probs;
+  int64_t* ep_len;
+  float* action;
+  float* prev_action;
+  int zero_action;
+  const float* log_prev;
+  float* log_out;
+  void* rewards_t;
+  void* dones_t1;
+  void* true_dones_t1;
+  int planes_f16;
+  const float* obs_raw;
+  int64_t obs_ld;
+  float* obs_mean;
+  float* obs_var;
+  float* obs_count;
+  float obs_eps;
+  double obs_n;
+  float* obs_out;
+  int64_t obs_out_ld;
+  const float* x_colmax;
+  const double* x_sums;
+  int x_records;          // > 1: x_colmax / x_sums point at record 0 of `x_records` gathered records, x_stride bytes apart
+  int64_t x_stride;
+  double* reset_part;     // [grid][2 n_terms + 1]: per term {sum violation, sum probability}, then the reset count
+  unsigned int* ticket;
+  int defer;              // 1: no tail in this launch (post_tail_deferred runs it from a later launch)
+};
+static_assert(sizeof(PostArgs) <= sizeof(catppo_ctx::post_tail_args), "catppo_ctx::post_tail_args too small");
+
+__device__ __forceinline__ void store_plane(void* p, int64_t i, float v, int f16) {
+  if (f16) reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
+  else reinterpret_cast<float*>(p)[i] = v;
+}
+
+// new running maximum of column c (constraint_manager.py:58-61) from the exchange record(s) and the state of the previous
+// step (every workgroup of rollout_post_kernel, into LDS; the last one to arrive writes it back)
+__device__ __forceinline__ float derive_running_max(const PostArgs& a, int c) {
+  float m = a.x_colmax[c];
+  for (int w = 1; w < a.x_records; ++w)     // gathered records of the other ranks: MAX is exact and order independent
+    m = nanmax(m, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_colmax) + w * a.x_stride)[c]);
+  if (a.first_call) return m;
+  const float x = a.rm[c] * a.tau;           // rm.mul_(tau)
+  const float y = a.one_minus_tau * m;       // (1-tau) * cmax
+  return x + y;                              // .add_()
+}
+// merged observation normaliser of column c (cleanrl/ppo.py:48-62, the op order of rms.hip): new mean / variance
+__device__ __forceinline__ void derive_normaliser(const PostArgs& a, int c, float cnt, float nf, float tot, float* new_mean,
+                                                  float* new_var) {
+  const int D = a.D;
+  double sx = a.x_sums[c], sxx = a.x_sums[D + c];
+  for (int w = 1; w < a.x_records; ++w) {   // rank order: the same sums on every rank
+    const double* xs = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x_sums) + w * a.x_stride);
+    sx += xs[c], sxx += xs[D + c];
+  }
+  const double m = sx / a.obs_n;
+  double v = sxx / a.obs_n - m * m;
+  if (v < 0.0) v = 0.0;
+  const float bm = (float)m, bv = (float)v;
+  const float mean = a.obs_mean[c];
+  const float delta = bm - mean;
+  float t = delta * nf;
+  t = t / tot;
+  *new_mean = mean + t;
+  const float m_a = a.obs_var[c] * cnt;
+  const float m_b = bv * nf;
+  float d2 = delta * delta;
+  d2 = d2 * cnt;
+  d2 = d2 * nf;
+  d2 = d2 / tot;
+  float M2 = m_a + m_b;
+  M2 = M2 + d2;
+  *new_var = M2 / tot;
+}
+
+// Reset statistics of a post launch: its `nblk` partial rows {sum violation, sum probability per term | number of envs
+// that reset} folded in ONE pass (the rows come from the coherence point, ~3.5 us per round trip - the count used to be
+// its own fold in front of this one) into the log slot.  One workgroup.
+__device__ __forceinline__ void fold_reset_log(const PostArgs& a, const int nblk, double* red) {
+  const int nt = a.n_terms;
+  __shared__ double s_sum[2 * kMaxTerms + 1];
+  block_fold<double>(a.reset_part, nblk, 2 * nt + 1, 0.0, [](double x, double y) { return x + y; }, red,
+                     [&](int c, double v) { s_sum[c] = v; });
+  const double n = s_sum[2 * nt];
+  if (threadIdx.x < 2 * nt) {
+    const int c = threadIdx.x;                  // column c = 2*t (violation) | 2*t+1 (probability)
+    const double v = s_sum[c];
+    if (n > 0.0) a.log_out[c] = (c & 1) ? (float)(v / n) : (float)(v / n) * 100.0f;
+    else if (a.log_prev != nullptr) a.log_out[c] = a.log_prev[c];
+  }
+}
+
+// The tail of a rollout_post launch when it is DEFERRED (catppo_rollout_defer_tail): run by one workgroup of a LATER
+// launch - the extra workgroup of the next rollout_pre, or rollout_post_tail_kernel - i.e. after every workgroup of the
+// post launch has finished, with nothing in between having touched the state or the exchange record(s).  The new running
+// maxima and the merged normaliser are derived once more - the same functions on the same inputs the post launch's
+// workgroups used - and published; then the reset statistics.  `red`: LDS, kThreads doubles.
+__device__ __forceinline__ void post_tail_deferred(const PostArgs& a, const int nblk, double* red) {
+  const int K = a.K, D = a.D;
+  for (int c = threadIdx.x; c < K; c += kThreads) a.rm[c] = derive_running_max(a, c);      // column c reads rm[c] only
+  if (a.obs_raw != nullptr) {
+    const float cnt = a.obs_count[0];
+    const float nf = (float)a.obs_n;
+    const float tot = cnt + nf;
+    for (int c = threadIdx.x; c < D; c += kThreads) {
+      float new_mean, new_var;
+      derive_normaliser(a, c, cnt, nf, tot, &new_mean, &new_var);
+      a.obs_mean[c] = new_mean, a.obs_var[c] = new_var;
+    }
+    __syncthreads();                            // every thread holds the old count
+    if (threadIdx.x == 0) a.obs_count[0] = tot;
+  }
+  if (a.log_out != nullptr) fold_reset_log(a, nblk, red);
+}
+
+__global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable tab, const PreArgs a, const PostArgs tl) {
   __shared__ double fold_lds[kThreads];
+  // one workgroup more than a.nblk: the deferred tail of the previous rollout_post launch (state it publishes is read by
+  // the NEXT post launch only; nothing the other workgroups of this launch touch)
+  if ((int)blockIdx.x == a.nblk) {
+    post_tail_deferred(tl, a.tail_nblk, fold_lds);
+    return;
+  }
   extern __shared__ float tile[];          // [kRows*K] constraint tile + [K] running column maxima
   float* cmax = tile + kRows * a.K;
   // the id lists of the terms, staged in LDS: the lane-varying lookup ids[j] is then an LDS read in front of the
@@ -175,8 +317,8 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
 
   const int64_t n_tiles = (a.N + kRows - 1) / kRows;
   RL_TL(0, 1);
-  for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
-    const int64_t r0 = tl * kRows;
+  for (int64_t tile_i = blockIdx.x; tile_i < n_tiles; tile_i += a.nblk) {
+    const int64_t r0 = tile_i * kRows;
     const int rows = (int)((a.N - r0) < kRows ? (a.N - r0) : kRows);
 
     // ---- simulator state advance: this tile's rows of the new state block go to the persistent state buffer.  Nothing
@@ -279,7 +421,7 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   // ---- fold tree, two levels, no extra launch: the last workgroup of every group of 32 folds the group's partial rows,
   //      the last of those folds the group rows into the exchange buffer.  Every fold is at most 32 rows deep, and the
   //      order of every sum depends only on the grid size - not on which workgroup happens to arrive last.
-  const int nblk = gridDim.x;
+  const int nblk = a.nblk;
   const int grp = blockIdx.x / kFoldGroup, n_grp = (nblk + kFoldGroup - 1) / kFoldGroup;
   const int g0 = grp * kFoldGroup, g_rows = (nblk - g0) < kFoldGroup ? (nblk - g0) : kFoldGroup;
   RL_TL(0, 3);
@@ -369,97 +511,14 @@ __global__ __launch_bounds__(256) void rollout_fold_kernel(const float* __restri
   }
 }
 
-struct TermMetaS {
-  int32_t off[kMaxTerms + 1];
-  float dp[kMaxTerms];
-};
-
-struct PostArgs {
-  int64_t N;
-  int A, D, K, n_terms;
-  const float* cstr;
-  float min_p, tau, one_minus_tau;
-  int first_call;
-  float* rm;
-  float* reward;
-  const uint8_t* reset;
-  const uint8_t* time_outs;
-  float* cstr_prob;
-  float* dones;
-  float* ep_viol;
-  float* ep_prob;
-  float* probs;
-  int64_t* ep_len;
-  float* action;
-  float* prev_action;
-  int zero_action;
-  const float* log_prev;
-  float* log_out;
-  void* rewards_t;
-  void* dones_t1;
-  void* true_dones_t1;
-  int planes_f16;
-  const float* obs_raw;
-  int64_t obs_ld;
-  float* obs_mean;
-  float* obs_var;
-  float* obs_count;
-  float obs_eps;
-  double obs_n;
-  float* obs_out;
-  int64_t obs_out_ld;
-  const float* x_colmax;
-  const double* x_sums;
-  int x_records;          // > 1: x_colmax / x_sums point at record 0 of `x_records` gathered records, x_stride bytes apart
-  int64_t x_stride;
-  double* reset_part;     // [grid][2 n_terms + 1]: per term {sum violation, sum probability}, then the reset count
-  unsigned int* ticket;
-};
-
-__device__ __forceinline__ void store_plane(void* p, int64_t i, float v, int f16) {
-  if (f16) reinterpret_cast<_Float16*>(p)[i] = (_Float16)v;
-  else reinterpret_cast<float*>(p)[i] = v;
-}
-
-// new running maximum of column c (constraint_manager.py:58-61) from the exchange record(s) and the state of the previous
-// step (every workgroup of rollout_post_kernel, into LDS; the last one to arrive writes it back)
-__device__ __forceinline__ float derive_running_max(const PostArgs& a, int c) {
-  float m = a.x_colmax[c];
-  for (int w = 1; w < a.x_records; ++w)     // gathered records of the other ranks: MAX is exact and order independent
-    m = nanmax(m, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_colmax) + w * a.x_stride)[c]);
-  if (a.first_call) return m;
-  const float x = a.rm[c] * a.tau;           // rm.mul_(tau)
-  const float y = a.one_minus_tau * m;       // (1-tau) * cmax
-  return x + y;                              // .add_()
-}
-// merged observation normaliser of column c (cleanrl/ppo.py:48-62, the op order of rms.hip): new mean / variance
-__device__ __forceinline__ void derive_normaliser(const PostArgs& a, int c, float cnt, float nf, float tot, float* new_mean,
-                                                  float* new_var) {
-  const int D = a.D;
-  double sx = a.x_sums[c], sxx = a.x_sums[D + c];
-  for (int w = 1; w < a.x_records; ++w) {   // rank order: the same sums on every rank
-    const double* xs = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x_sums) + w * a.x_stride);
-    sx += xs[c], sxx += xs[D + c];
-  }
-  const double m = sx / a.obs_n;
-  double v = sxx / a.obs_n - m * m;
-  if (v < 0.0) v = 0.0;
-  const float bm = (float)m, bv = (float)v;
-  const float mean = a.obs_mean[c];
-  const float delta = bm - mean;
-  float t = delta * nf;
-  t = t / tot;
-  *new_mean = mean + t;
-  const float m_a = a.obs_var[c] * cnt;
-  const float m_b = bv * nf;
-  float d2 = delta * delta;
-  d2 = d2 * cnt;
-  d2 = d2 * nf;
-  d2 = d2 / tot;
-  float M2 = m_a + m_b;
-  M2 = M2 + d2;
-  *new_var = M2 / tot;
-}
+// Round 5: every load whose address does not depend on another load is requested at the top of the kernel, before the
+// first barrier (tiles of the usual sizes: the generic loops below remain for wide constraint tables / observations).
+// The kernel is a handful of dependent steps separated by barriers, and the compiler cannot move a load across one: the
+// constraint tile, the episode statistics, the per-env bytes and the raw observation rows each used to pay their own
+// memory round trip behind the barrier in front of them - four in sequence, on the chain of every env step.
+constexpr int kPreC = 4;      // constraint elements per thread held in registers: 32 rows x K <= 1024
+constexpr int kPreO = 8;      // observation elements per thread: 32 rows x D <= 2048
+constexpr int kPreW = 2;      // (term, env) pairs per thread: n_terms <= 16
 
 __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a, const TermMetaS meta) {
   extern __shared__ float smem[];
@@ -476,6 +535,57 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
   __shared__ float s_tot;
 
   RL_TL(1, 0);
+  const int64_t r0 = (int64_t)blockIdx.x * kPostRows;
+  const int rows = (int)((a.N - r0) < kPostRows ? (a.N - r0) : kPostRows);
+  const int n_el = rows * K;
+  const float* src = a.cstr + r0 * K;
+  // ---- requests up front
+  const bool pre_c = n_el <= kPreC * kThreads;
+  const bool pre_o = a.obs_raw != nullptr && rows * D <= kPreO * kThreads;
+  float pc[kPreC], po[kPreO];
+  if (pre_c) {
+#pragma unroll
+    for (int j = 0; j < kPreC; ++j) {
+      const int e = threadIdx.x + j * kThreads;
+      pc[j] = e < n_el ? src[e] : 0.0f;
+    }
+  }
+  if (pre_o) {
+#pragma unroll
+    for (int j = 0; j < kPreO; ++j) {
+      const int e = threadIdx.x + j * kThreads;
+      po[j] = 0.0f;
+      if (e < rows * D) {
+        const int r = e / D, c = e - r * D;
+        po[j] = a.obs_raw[(r0 + r) * a.obs_ld + c];
+      }
+    }
+  }
+  float pw_v[kPreW], pw_p[kPreW], pw_L[kPreW];
+  bool pw_rs[kPreW];
+#pragma unroll
+  for (int j = 0; j < kPreW; ++j) {
+    const int w = threadIdx.x + j * kThreads;
+    const int t = w / kPostRows, e = w - t * kPostRows;
+    pw_v[j] = 0.0f, pw_p[j] = 0.0f, pw_L[j] = 1.0f, pw_rs[j] = false;
+    if (w < nt * kPostRows && e < rows) {
+      const int64_t i = r0 + e;
+      const int64_t gi = (int64_t)t * a.N + i;
+      pw_v[j] = a.ep_viol[gi];
+      pw_p[j] = a.ep_prob[gi];
+      pw_rs[j] = a.reset[i] != 0;
+      pw_L[j] = (float)a.ep_len[i];
+    }
+  }
+  float pe_reward = 0.0f;
+  bool pe_rs = false, pe_to = false;
+  if (threadIdx.x < rows) {
+    const int64_t i = r0 + threadIdx.x;
+    pe_reward = a.reward[i];
+    pe_rs = a.reset[i] != 0;
+    pe_to = a.time_outs[i] != 0;
+  }
+
   if (threadIdx.x <= nt) s_off[threadIdx.x] = meta.off[threadIdx.x];
   __syncthreads();
   // ---- new running maxima (constraint_manager.py:58-61), identical in every workgroup
@@ -502,14 +612,8 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
   __syncthreads();
   RL_TL(1, 1);
 
-  const int64_t r0 = (int64_t)blockIdx.x * kPostRows;
-  const int rows = (int)((a.N - r0) < kPostRows ? (a.N - r0) : kPostRows);
-  const int n_el = rows * K;
-  const float* src = a.cstr + r0 * K;
   float* pdst = a.probs ? a.probs + r0 * K : nullptr;
-  for (int e = threadIdx.x; e < n_el; e += kThreads) {
-    const int c = e % K;
-    const float x = src[e];
+  auto prob_of = [&](const float x, const int c) {
     float p = 0.0f;
     if (x > 0.0f) {
       float q = x / col_rm[c];
@@ -517,13 +621,29 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
       const float s = q * col_dp[c];
       p = a.min_p + s;
     }
-    tile[e] = p;
-    if (pdst) pdst[e] = p;
+    return p;
+  };
+  if (pre_c) {
+#pragma unroll
+    for (int j = 0; j < kPreC; ++j) {
+      const int e = threadIdx.x + j * kThreads;
+      if (e < n_el) {
+        const float p = prob_of(pc[j], e % K);
+        tile[e] = p;
+        if (pdst) pdst[e] = p;
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < n_el; e += kThreads) {
+      const float p = prob_of(src[e], e % K);
+      tile[e] = p;
+      if (pdst) pdst[e] = p;
+    }
   }
   __syncthreads();
 
   // ---- per (term, env): max over the term's columns, episode statistics, reset statistics
-  for (int w = threadIdx.x; w < nt * kPostRows; w += kThreads) {
+  auto term_env = [&](const int w, const float v_in, const float p_in, const bool rs, const float L) {
     const int t = w / kPostRows, e = w - t * kPostRows;
     double ra = 0.0, rb = 0.0;
     if (e < rows) {
@@ -531,12 +651,10 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
       float m = row[s_off[t]];
       for (int c = s_off[t] + 1; c < s_off[t + 1]; ++c) m = nanmax(m, row[c]);
       tmax[t * kPostRows + e] = m;
-      const int64_t i = r0 + e;
-      const int64_t gi = (int64_t)t * a.N + i;
-      float v = a.ep_viol[gi] + (m > 0.0f ? 1.0f : 0.0f);
-      float p = a.ep_prob[gi] + m;
-      if (a.reset[i]) {          // ConstraintManager.reset (constraint_manager.py:190-211) for the envs that reset
-        const float L = (float)a.ep_len[i];
+      const int64_t gi = (int64_t)t * a.N + r0 + e;
+      float v = v_in + (m > 0.0f ? 1.0f : 0.0f);
+      float p = p_in + m;
+      if (rs) {          // ConstraintManager.reset (constraint_manager.py:190-211) for the envs that reset
         ra = (double)(v / L);
         rb = (double)(p / L);
         v = 0.0f, p = 0.0f;
@@ -546,6 +664,16 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     }
     red[w] = ra;
     red[nt * kPostRows + w] = rb;
+  };
+#pragma unroll
+  for (int j = 0; j < kPreW; ++j) {
+    const int w = threadIdx.x + j * kThreads;
+    if (w < nt * kPostRows) term_env(w, pw_v[j], pw_p[j], pw_rs[j], pw_L[j]);
+  }
+  for (int w = threadIdx.x + kPreW * kThreads; w < nt * kPostRows; w += kThreads) {     // (n_terms <= 16: never taken)
+    const int t = w / kPostRows, e = w - t * kPostRows;
+    const int64_t i = r0 + (e < rows ? e : 0);
+    term_env(w, a.ep_viol[(int64_t)t * a.N + i], a.ep_prob[(int64_t)t * a.N + i], a.reset[i] != 0, (float)a.ep_len[i]);
   }
   __syncthreads();
   if (threadIdx.x < nt) {
@@ -563,10 +691,10 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     const int64_t i = r0 + e;
     a.cstr_prob[i] = p;
     const float omp = 1.0f - p;
-    float r = a.reward[i] * omp;
+    float r = pe_reward * omp;
     r = (r < 0.0f) ? 0.0f : r;
     a.reward[i] = r;
-    const bool rs = a.reset[i] != 0;
+    const bool rs = pe_rs;
     {   // envs of this tile that reset: rows <= 32 live in the first half of wave 0
       const unsigned long long mask = __ballot(rs);
       if (threadIdx.x == 0) xwg_store(a.reset_part + (int64_t)blockIdx.x * (2 * nt + 1) + 2 * nt, (double)__popcll(mask));
@@ -576,7 +704,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     if (a.rewards_t != nullptr) {
       store_plane(a.rewards_t, i, r, a.planes_f16);
       store_plane(a.dones_t1, i, dn, a.planes_f16);
-      store_plane(a.true_dones_t1, i, a.time_outs[i] ? 1.0f : 0.0f, a.planes_f16);
+      store_plane(a.true_dones_t1, i, pe_to ? 1.0f : 0.0f, a.planes_f16);
     }
     if (rs) {
       a.ep_len[i] = 0;
@@ -586,7 +714,17 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     }
   }
   // ---- normalised next observation rows
-  if (a.obs_raw != nullptr) {
+  if (pre_o) {
+#pragma unroll
+    for (int j = 0; j < kPreO; ++j) {
+      const int e = threadIdx.x + j * kThreads;
+      if (e < rows * D) {
+        const int r = e / D, c = e - r * D;
+        const float v = po[j] - s_mean[c];
+        a.obs_out[(r0 + r) * a.obs_out_ld + c] = v / s_den[c];
+      }
+    }
+  } else if (a.obs_raw != nullptr) {
     for (int e = threadIdx.x; e < rows * D; e += kThreads) {
       const int r = e / D, c = e - r * D;
       const float v = a.obs_raw[(r0 + r) * a.obs_ld + c] - s_mean[c];
@@ -594,6 +732,9 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     }
   }
   RL_TL(1, 2);
+  // deferred tail (catppo_rollout_defer_tail): this launch ends here - no hand-shake; one workgroup of the next
+  // rollout_pre launch derives the new state once more and publishes it, and folds the rows written above
+  if (a.defer) return;
   // (round 4 measured this tail as a one-workgroup launch of its own, like rollout_fold_kernel behind the pre kernel:
   // 1.51 against 1.44 ms per rollout - its work is a chain of three dependent memory round trips either way, and here
   // only ONE hand-shake stands in front of it, not two - so it stays with the last workgroup to arrive)
@@ -606,22 +747,14 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     for (int c = threadIdx.x; c < D; c += kThreads) a.obs_mean[c] = s_mean[c], a.obs_var[c] = s_var[c];
     if (threadIdx.x == 0) a.obs_count[0] = s_tot;
   }
-  if (a.log_out != nullptr) {
-    // one pass over the partial rows {sum violation, sum probability per term | number of envs that reset}: the rows
-    // come from the coherence point (~3.5 us per round trip) - the count used to be its own fold in front of this one
-    const int nblk = gridDim.x;
-    __shared__ double s_sum[2 * kMaxTerms + 1];
-    block_fold<double>(a.reset_part, nblk, 2 * nt + 1, 0.0, [](double x, double y) { return x + y; }, red,
-                       [&](int c, double v) { s_sum[c] = v; });
-    const double n = s_sum[2 * nt];
-    if (threadIdx.x < 2 * nt) {
-      const int c = threadIdx.x;                  // column c = 2*t (violation) | 2*t+1 (probability)
-      const double v = s_sum[c];
-      if (n > 0.0) a.log_out[c] = (c & 1) ? (float)(v / n) : (float)(v / n) * 100.0f;
-      else if (a.log_prev != nullptr) a.log_out[c] = a.log_prev[c];
-    }
-  }
+  if (a.log_out != nullptr) fold_reset_log(a, gridDim.x, red);
   RL_TL(1, 4);
+}
+
+// the deferred tail as a launch of its own: catppo_rollout_flush, or a post call that finds a tail still pending
+__global__ __launch_bounds__(kThreads) void rollout_post_tail_kernel(const PostArgs a, const int nblk) {
+  __shared__ double red[kThreads];
+  post_tail_deferred(a, nblk, red);
 }
 
 #ifdef ROLLOUT_TL
@@ -632,6 +765,20 @@ extern "C" int catppo_debug_rollout_tl(void* buf) {     // timeline builds only:
 #endif
 
 inline uint64_t xchg_sum_offset(int K) { return ((uint64_t)K * sizeof(float) + 15) / 16 * 16; }
+
+// a deferred post tail that no rollout_pre launch picked up: one small launch of its own
+int flush_post_tail(catppo_ctx* ctx, hipStream_t stream) {
+  if (!ctx->post_tail_pending) return CATPPO_OK;
+  PostArgs tl;
+  memcpy(&tl, ctx->post_tail_args, sizeof(tl));
+  // the tail belongs behind the post launch: on the stream that launch went to, whatever the caller passes now
+  (void)stream;
+  hipLaunchKernelGGL(rollout_post_tail_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(ctx->post_tail_stream),
+                     tl, ctx->post_tail_nblk);
+  ctx->post_tail_pending = false;
+  CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
 
 int check_step(catppo_ctx* ctx, const catppo_rollout_step* a, const char* fn) {
   if (!ctx) return CATPPO_E_ARG;
@@ -746,8 +893,24 @@ extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a,
   // rollout_fold_kernel - A/B switch
   static const bool tree = [] { const char* e = getenv("CATPPO_ROLLOUT_TREE"); return e && e[0] == '1'; }();
   p.tree = tree ? 1 : 0;
-  hipLaunchKernelGGL(rollout_pre_kernel, dim3((unsigned)nblk), dim3(kThreads), lds, static_cast<hipStream_t>(stream), tab,
-                     p);
+  p.nblk = (int)nblk;
+  // the deferred tail of the previous rollout_post launch rides along as one more workgroup (same stream: it must run
+  // behind that launch; another stream gets the tail as a launch of its own, on the stream of the post launch)
+  PostArgs tl{};
+  int extra = 0;
+  if (ctx->post_tail_pending) {
+    // (the in-launch fold tree of CATPPO_ROLLOUT_TREE=1 writes the exchange record the tail still reads: no ride then)
+    if (ctx->post_tail_stream == stream && !tree) {
+      memcpy(&tl, ctx->post_tail_args, sizeof(tl));
+      p.tail_nblk = ctx->post_tail_nblk;
+      ctx->post_tail_pending = false;
+      extra = 1;
+    } else if (int rc = flush_post_tail(ctx, static_cast<hipStream_t>(stream))) {
+      return rc;
+    }
+  }
+  hipLaunchKernelGGL(rollout_pre_kernel, dim3((unsigned)nblk + extra), dim3(kThreads), lds, static_cast<hipStream_t>(stream),
+                     tab, p, tl);
   CATPPO_CHECK_LAUNCH(ctx);
   if (!tree) {
     const int K16 = (a->K + 15) / 16 * 16, D2 = a->obs_raw != nullptr ? 2 * a->D : 0;
@@ -780,9 +943,26 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   const size_t lds = sizeof(float) * ((size_t)2 * K + (size_t)kPostRows * K + (size_t)nt * kPostRows + (size_t)3 * D);
   if (lds > 140 * 1024) return catppo_fail(ctx, CATPPO_E_ARG, "rollout_post: K=%d / D=%d too wide for one LDS tile", K, D);
   const int nblk = (int)cdiv64(a->N, kPostRows);
-  WsCarver ws(ctx);
-  double* rpart = ws.take<double>((uint64_t)nblk * (nt * 2 + 1));
-  CATPPO_NEED_WS(ctx, rpart);
+  // a tail still pending (two post calls with no pre call between them): it reads the state this launch is about to read
+  if (int rc = flush_post_tail(ctx, static_cast<hipStream_t>(stream))) return rc;
+  const bool defer = ctx->rollout_defer;
+  double* rpart = nullptr;
+  if (defer) {
+    // the rows outlive this call (the workspace is anybody's between two launches): a buffer of the context
+    const uint64_t need = (uint64_t)nblk * (nt * 2 + 1) * sizeof(double);
+    if (need > ctx->post_rpart_bytes) {
+      if (ctx->post_rpart) (void)hipFree(ctx->post_rpart);     // (synchronises: nobody reads the old rows any more)
+      ctx->post_rpart = nullptr, ctx->post_rpart_bytes = 0;
+      if (hipMalloc(reinterpret_cast<void**>(&ctx->post_rpart), need) != hipSuccess)
+        return catppo_fail(ctx, CATPPO_E_HIP, "catppo_rollout_post: hipMalloc of %llu B failed", (unsigned long long)need);
+      ctx->post_rpart_bytes = need;
+    }
+    rpart = ctx->post_rpart;
+  } else {
+    WsCarver ws(ctx);
+    rpart = ws.take<double>((uint64_t)nblk * (nt * 2 + 1));
+    CATPPO_NEED_WS(ctx, rpart);
+  }
   PostArgs p{};
   p.N = a->N, p.A = a->A, p.D = D, p.K = K, p.n_terms = nt;
   p.cstr = a->cstr;
@@ -805,10 +985,29 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   p.x_stride = (int64_t)(xchg_sum_offset(K) + (uint64_t)2 * (a->D > 0 ? a->D : 1) * sizeof(double));
   p.reset_part = rpart;
   p.ticket = ctx->tickets + catppo_ctx::kTicketPost;
+  p.defer = defer ? 1 : 0;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_post_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(rollout_post_kernel, dim3(nblk), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p, meta);
   CATPPO_CHECK_LAUNCH(ctx);
+  if (defer) {
+    memcpy(ctx->post_tail_args, &p, sizeof(p));
+    ctx->post_tail_nblk = nblk;
+    ctx->post_tail_stream = stream;
+    ctx->post_tail_pending = true;
+  }
   return CATPPO_OK;
+}
+
+extern "C" int catppo_rollout_flush(catppo_ctx* ctx, void* stream) {
+  if (!ctx) return CATPPO_E_ARG;
+  return flush_post_tail(ctx, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int catppo_rollout_defer_tail(catppo_ctx* ctx, int on, void* stream) {
+  if (!ctx) return CATPPO_E_ARG;
+  CATPPO_CHECK_ARG(ctx, on == 0 || on == 1);
+  ctx->rollout_defer = on != 0;
+  return on ? CATPPO_OK : flush_post_tail(ctx, static_cast<hipStream_t>(stream));
 }

@@ -557,6 +557,22 @@ uint64_t catppo_rollout_step_sizeof(void);   /* sizeof(catppo_rollout_step): let
 uint64_t catppo_rollout_xchg_sum_offset(int K);
 int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
 int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
+/* ABI 0.5: the tail of catppo_rollout_post - ONE workgroup that, after all others, publishes the new running maxima (rm)
+ * and observation-normaliser state (obs_mean / obs_var / obs_count) and folds the reset statistics into log_out - off the
+ * chain forward -> pre -> fold -> post -> forward of an env step.  With on = 1 a post launch ends without that tail (and
+ * without the "last workgroup arrives" hand-shake in front of it); the tail runs as one more workgroup of the NEXT
+ * catppo_rollout_pre launch on the same stream (nothing in between reads what it writes: the policy forward consumes
+ * obs_out, the simulator its own state), or as a launch of its own from catppo_rollout_flush / the next
+ * catppo_rollout_post / catppo_rollout_defer_tail(ctx, 0, stream).  CONTRACT while on: rm, obs_mean, obs_var, obs_count
+ * and log_out of a step are valid (in stream order) only after one of those calls; every other output of the step is
+ * valid after catppo_rollout_post as before.  Values are bit-identical either way: the tail derives the state with the same
+ * device functions from the same exchange record(s) - which must stay untouched until then (they are: the next writer is
+ * the fold behind the next catppo_rollout_pre / the next all-gather).  The rollout loop of cleanrl/ppo.py's PPOTrainer
+ * switches it on around its env steps and off (= flush) before GAE.  Reference: the statistics concerned are
+ * ConstraintManager's running maxima (cat/constraint_manager.py:58-61), RunningMeanStd's state (cleanrl/ppo.py:48-62)
+ * and the episode log of ConstraintManager.reset (cat/constraint_manager.py:190-211). */
+int catppo_rollout_defer_tail(catppo_ctx* ctx, int on, void* stream);
+int catppo_rollout_flush(catppo_ctx* ctx, void* stream);
 
 /* ---- rl_games front end: episode bookkeeping with float dones ---------------------------------------
  * One env step of CaTA2CAgent.play_steps' bookkeeping (rl_games/cat_common.py:71-92), one launch, no host sync:

@@ -349,3 +349,104 @@ def test_gradient_tail_reduced_under_the_final_fold_launch_world_of_one():
     for obs in (48, 235):
         r = r4._run_code(code.replace("obs_dim=48", f"obs_dim={obs}"))
         assert r.returncode == 0 and "TAIL-OK" in r.stdout, (obs, r.stdout[-2000:] + r.stderr[-4000:])
+
+
+# ------------------------------------------------------------------------------------------ deferred post tail
+_DEFER_CODE = r"""
+import os, sys, torch, numpy as np
+dist = os.environ.get('CATPPO_FORCE_DIST') == '1'
+if dist:
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['TEST_PORT'], RANK='0', WORLD_SIZE='1')
+import smoke_impl
+from cat_envs import parallel
+if dist:
+    parallel.init_rendezvous(0)
+from cat_envs.shim import make
+from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+task, env_cfg, agent_cfg = smoke_impl.make_cfgs(int(os.environ['T_ENVS']), 12, 2048, 2, 50, (256, 256, 256), False,
+                                                obs_dim=int(os.environ['T_OBS']), seed=5)
+torch.manual_seed(3)
+env = make(task, cfg=env_cfg)
+tr = PPOTrainer(env, agent_cfg)
+assert tr.defer_tail == (os.environ['CATPPO_ROLLOUT_DEFER_TAIL'] == '1')
+logs = []
+for _ in range(3):
+    logs.append(tr.run_iteration(log=True))
+torch.cuda.synchronize()
+assert not tr.nat.lib.catppo_rollout_flush(tr.nat.h, tr.nat._stream())           # nothing pending after a rollout
+eu = env.unwrapped
+cm = eu.constraint_manager
+rms = tr.agent.obs_rms
+np.savez(os.environ['T_OUT'], flat=tr.agent.flat.cpu().numpy(), dones=tr.dones.float().cpu().numpy(),
+         rewards=tr.rewards.float().cpu().numpy(), obs=tr.obs.cpu().numpy(), act=tr.actions.cpu().numpy(),
+         values=tr.values.float().cpu().numpy(), cstr=cm.cat._p_cstr.cpu().numpy(), rm=cm.cat._p_rm.cpu().numpy(),
+         probs=cm.cat._p_probs.cpu().numpy(), ring=cm._log_ring.cpu().numpy(), ep_viol=cm._ep_viol.cpu().numpy(),
+         ep_prob=cm._ep_prob.cpu().numpy(), mean=rms.running_mean.cpu().numpy(), var=rms.running_var.cpu().numpy(),
+         count=rms.count.cpu().numpy(), state=eu.sim.cur.cpu().numpy(), ep_len=eu.episode_length_buf.cpu().numpy())
+print('DEFER-OK', tr.sink is not None, float(rms.count))
+if dist:
+    parallel.shutdown_native_comm()
+    torch.distributed.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("envs,obs,dist", [(777, 45, "0"), (4096, 48, "0"), (512, 48, "1"), (96, 235, "0")])
+def test_post_tail_deferred_into_the_next_pre_launch_is_bit_identical(tmp_path, envs, obs, dist):
+    """catppo_rollout_defer_tail (ABI 0.5): the one-workgroup tail of catppo_rollout_post (running
+    maxima of cat/constraint_manager.py:58-61, the normaliser state of cleanrl/ppo.py:48-62, the episode log of
+    constraint_manager.py:190-211) run by one more workgroup of the NEXT catppo_rollout_pre launch - against the tail
+    inside the post launch: three iterations, every buffer and every piece of state BIT-identical; also with every
+    exchange point forced on over a world of one (gathered exchange records)."""
+    outs = []
+    for flag in ("1", "0"):
+        out = str(tmp_path / f"defer{flag}.npz")
+        r = _run_code(_DEFER_CODE, T_OUT=out, CATPPO_ROLLOUT_DEFER_TAIL=flag, CATPPO_FORCE_DIST=dist, T_ENVS=str(envs),
+                      T_OBS=str(obs))
+        assert r.returncode == 0 and "DEFER-OK True" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        outs.append(np.load(out))
+    for k in outs[0].files:
+        np.testing.assert_array_equal(outs[0][k], outs[1][k], err_msg=k)
+    assert np.abs(outs[0]["ring"]).sum() > 0 and outs[0]["dones"].max() > 0 and float(outs[0]["count"]) > 3 * 12 * envs
+
+
+def test_deferred_post_tail_contract_through_the_c_abi():
+    """the state a deferred tail publishes is current after catppo_rollout_flush; a second catppo_rollout_post with the
+    tail still pending runs it first (on its own launch); switching the deferral off flushes"""
+    import smoke_impl
+    from cat_envs.shim import make
+    from cat_envs.tasks.utils.cleanrl.ppo import PPOTrainer
+    res = {}
+    for mode in ("inline", "deferred"):
+        # (a fresh config per env: the curriculum edits the terms' max_p in place)
+        task, env_cfg, agent_cfg = smoke_impl.make_cfgs(200, 4, 400, 1, 5, (256, 256), True, obs_dim=48, seed=3)
+        torch.manual_seed(3)
+        env = make(task, cfg=env_cfg)
+        tr = PPOTrainer(env, agent_cfg)
+        tr.defer_tail = False
+        tr.run_iteration(log=False)                    # fills the argument block of the fused step
+        torch.cuda.synchronize()
+        eu, nat = env.unwrapped, tr.nat
+        cm, rms = eu.constraint_manager, tr.agent.obs_rms
+        if mode == "deferred":
+            nat.rollout_defer_tail(True)
+        snaps = []
+        for k in range(3):                             # the same argument block three times: pre, fold, post
+            assert nat.lib.catppo_rollout_pre(nat.h, eu._rstep_ref, nat._stream()) == 0
+            assert nat.lib.catppo_rollout_post(nat.h, eu._rstep_ref, nat._stream()) == 0
+            if k == 1:                                 # post, post: the pending tail of the first runs in front of the second
+                assert nat.lib.catppo_rollout_post(nat.h, eu._rstep_ref, nat._stream()) == 0
+            if mode == "deferred" and k == 0:
+                torch.cuda.synchronize()
+                stale = cm.cat._p_rm.clone()           # not yet published ...
+                nat.rollout_flush()
+                torch.cuda.synchronize()               # ... now it is
+                snaps.append(("flush_changed_rm", not torch.equal(stale, cm.cat._p_rm)))
+        if mode == "deferred":
+            nat.rollout_defer_tail(False)              # = flush
+        torch.cuda.synchronize()
+        res[mode] = dict(rm=cm.cat._p_rm.cpu().numpy().copy(), mean=rms.running_mean.cpu().numpy().copy(),
+                         var=rms.running_var.cpu().numpy().copy(), count=rms.count.cpu().numpy().copy(),
+                         ring=cm._log_ring.cpu().numpy().copy(), ep_viol=cm._ep_viol.cpu().numpy().copy(), snaps=snaps)
+    for k in ("rm", "mean", "var", "count", "ring", "ep_viol"):
+        np.testing.assert_array_equal(res["inline"][k], res["deferred"][k], err_msg=k)
+    assert res["deferred"]["snaps"] == [("flush_changed_rm", True)]
