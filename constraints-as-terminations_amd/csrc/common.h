@@ -113,6 +113,13 @@ struct WsCarver {
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Division of a small index by a run-time width without the ~35-instruction integer-division sequence (no hardware
+// divider on gfx9): q = mulhi(e, magic), magic = floor(2^32 / d) + 1.  Exact whenever e * d < 2^32 - here e < 2^17 and
+// d <= 4096 (checked exhaustively over that whole range on the host); d == 1 is encoded as magic 0.  The launch-bound
+// kernels of the env step (one wave per SIMD: every instruction is latency) spent ~20 such divisions per thread.
+static inline uint32_t catppo_div_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((uint64_t(1) << 32) / d) + 1u; }
+__device__ __forceinline__ int fast_div(int e, uint32_t magic) { return magic ? (int)__umulhi((uint32_t)e, magic) : e; }
+
 // cat_terms.hip: evaluate the term table into cstr[N,K]; with `colmax_partial` ([<=256][K], may be null) every
 // workgroup also writes the column maxima of the rows it produced, *nblk_out = number of partial rows
 int catppo_internal_launch_terms(catppo_ctx* ctx, const catppo_term_desc* desc, int n_terms, int64_t N,

@@ -199,6 +199,7 @@ struct PostArgs {
   double* reset_part;     // [grid][2 n_terms + 1]: per term {sum violation, sum probability}, then the reset count
   unsigned int* ticket;
   int defer;              // 1: no tail in this launch (post_tail_deferred runs it from a later launch)
+  uint32_t d_magic, k_magic;   // catppo_div_magic(D), (K)
 };
 static_assert(sizeof(PostArgs) <= sizeof(catppo_ctx::post_tail_args), "catppo_ctx::post_tail_args too small");
 
@@ -208,35 +209,44 @@ __device__ __forceinline__ void store_plane(void* p, int64_t i, float v, int f16
 }
 
 // new running maximum of column c (constraint_manager.py:58-61) from the exchange record(s) and the state of the previous
-// step (every workgroup of rollout_post_kernel, into LDS; the last one to arrive writes it back)
-__device__ __forceinline__ float derive_running_max(const PostArgs& a, int c) {
+// step (every workgroup of rollout_post_kernel, into LDS; the last one to arrive - or the deferred tail - writes it back).
+// Split into the loads and the arithmetic so that rollout_post_kernel can request the operands up front.
+__device__ __forceinline__ float load_colmax(const PostArgs& a, int c) {
   float m = a.x_colmax[c];
   for (int w = 1; w < a.x_records; ++w)     // gathered records of the other ranks: MAX is exact and order independent
     m = nanmax(m, reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.x_colmax) + w * a.x_stride)[c]);
+  return m;
+}
+__device__ __forceinline__ float running_max_from(const PostArgs& a, float m, float rm_c) {
   if (a.first_call) return m;
-  const float x = a.rm[c] * a.tau;           // rm.mul_(tau)
+  const float x = rm_c * a.tau;              // rm.mul_(tau)
   const float y = a.one_minus_tau * m;       // (1-tau) * cmax
   return x + y;                              // .add_()
 }
+__device__ __forceinline__ float derive_running_max(const PostArgs& a, int c) {
+  return running_max_from(a, load_colmax(a, c), a.first_call ? 0.0f : a.rm[c]);
+}
 // merged observation normaliser of column c (cleanrl/ppo.py:48-62, the op order of rms.hip): new mean / variance
-__device__ __forceinline__ void derive_normaliser(const PostArgs& a, int c, float cnt, float nf, float tot, float* new_mean,
-                                                  float* new_var) {
+__device__ __forceinline__ void load_sums(const PostArgs& a, int c, double* sx_out, double* sxx_out) {
   const int D = a.D;
   double sx = a.x_sums[c], sxx = a.x_sums[D + c];
   for (int w = 1; w < a.x_records; ++w) {   // rank order: the same sums on every rank
     const double* xs = reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.x_sums) + w * a.x_stride);
     sx += xs[c], sxx += xs[D + c];
   }
+  *sx_out = sx, *sxx_out = sxx;
+}
+__device__ __forceinline__ void normaliser_from(const PostArgs& a, double sx, double sxx, float mean, float var, float cnt,
+                                                float nf, float tot, float* new_mean, float* new_var) {
   const double m = sx / a.obs_n;
   double v = sxx / a.obs_n - m * m;
   if (v < 0.0) v = 0.0;
   const float bm = (float)m, bv = (float)v;
-  const float mean = a.obs_mean[c];
   const float delta = bm - mean;
   float t = delta * nf;
   t = t / tot;
   *new_mean = mean + t;
-  const float m_a = a.obs_var[c] * cnt;
+  const float m_a = var * cnt;
   const float m_b = bv * nf;
   float d2 = delta * delta;
   d2 = d2 * cnt;
@@ -245,6 +255,12 @@ __device__ __forceinline__ void derive_normaliser(const PostArgs& a, int c, floa
   float M2 = m_a + m_b;
   M2 = M2 + d2;
   *new_var = M2 / tot;
+}
+__device__ __forceinline__ void derive_normaliser(const PostArgs& a, int c, float cnt, float nf, float tot, float* new_mean,
+                                                  float* new_var) {
+  double sx, sxx;
+  load_sums(a, c, &sx, &sxx);
+  normaliser_from(a, sx, sxx, a.obs_mean[c], a.obs_var[c], cnt, nf, tot, new_mean, new_var);
 }
 
 // Reset statistics of a post launch: its `nblk` partial rows {sum violation, sum probability per term | number of envs
@@ -301,7 +317,9 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
   // state load instead of a second global-memory round trip through the kernel-argument segment
   __shared__ int s_ids[kMaxTerms][CATPPO_TERM_MAX_IDS];
   const int K = a.K, A = a.A, D = a.D;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (the wave index as a scalar: tab.d[t] below is then read with scalar loads - their own counter - instead of vector
+  //  loads from the kernel-argument segment that would queue up behind the state copy's requests)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   RL_TL(0, 0);
   for (int c = threadIdx.x; c < K; c += kThreads) cmax[c] = -__builtin_inff();
   for (int o = threadIdx.x; o < tab.n * CATPPO_TERM_MAX_IDS; o += kThreads)
@@ -324,9 +342,24 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
     // ---- simulator state advance: this tile's rows of the new state block go to the persistent state buffer.  Nothing
     //      in this launch reads the destination (every state input has been re-based onto the source by the host side),
     //      so the copy is independent traffic beside the dependent load chains of the terms below.
-    if (a.sim_src != nullptr) {
-      const int64_t base = r0 * a.sim_row_q4;
-      for (int e = threadIdx.x; e < rows * a.sim_row_q4; e += kThreads) a.sim_dst[base + e] = a.sim_src[base + e];
+    //      Round 5: the rows are REQUESTED here (which also brings the lines the terms read into the CU's cache) and
+    //      stored behind the terms: gfx9 counts loads and stores in one in-order counter, so with the stores in front
+    //      every wait of the term loads below also waited for the copy's stores to reach memory.
+    constexpr int kCopyQ = 8;                       // float4 per thread held in registers: 16 rows x 2 KB
+    const int copy_n = a.sim_src != nullptr ? rows * a.sim_row_q4 : 0;
+    const bool copy_regs = copy_n <= kCopyQ * kThreads;
+    const int64_t copy_base = r0 * a.sim_row_q4;
+    // (a native vector type: arrays of HIP's float4 struct are copied through memcpy and end up in scratch)
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v* copy_src = reinterpret_cast<const f4v*>(a.sim_src) + copy_base;
+    f4v* copy_dst = reinterpret_cast<f4v*>(a.sim_dst) + copy_base;
+    f4v cq[kCopyQ];
+    if (copy_regs) {
+#pragma unroll
+      for (int j = 0; j < kCopyQ; ++j) {
+        const int e = threadIdx.x + j * kThreads;
+        cq[j] = e < copy_n ? copy_src[e] : f4v{0.0f, 0.0f, 0.0f, 0.0f};
+      }
     }
 
     // ---- constraint terms (the action-rate term reads action_in / the not yet shifted action buffer)
@@ -334,8 +367,9 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
       const catppo_term_desc& d = tab.d[t];
       const int W = d.width;
       const int col0 = tab.off[t];
+      const uint32_t wm = tab.wmagic[t];
       for (int w = lane; w < rows * W; w += 64) {
-        const int e = w / W, j = w - e * W;
+        const int e = fast_div(w, wm), j = w - e * W;
         tile[e * K + col0 + j] = eval_term(d, s_ids[t], r0 + e, j, a.forces, a.fstride, a.H, a.B, a.command, a.cld);
       }
     }
@@ -379,6 +413,15 @@ __global__ __launch_bounds__(kThreads) void rollout_pre_kernel(const TermTable t
       }
     }
     RL_TL(0, 11);
+    if (copy_regs) {
+#pragma unroll
+      for (int j = 0; j < kCopyQ; ++j) {
+        const int e = threadIdx.x + j * kThreads;
+        if (e < copy_n) copy_dst[e] = cq[j];
+      }
+    } else {
+      for (int e = threadIdx.x; e < copy_n; e += kThreads) copy_dst[e] = copy_src[e];
+    }
     __syncthreads();
     RL_TL(0, 12);
     // ---- flush the tile, running column maxima, and only now shift the action history (process_action)
@@ -556,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
       const int e = threadIdx.x + j * kThreads;
       po[j] = 0.0f;
       if (e < rows * D) {
-        const int r = e / D, c = e - r * D;
+        const int r = fast_div(e, a.d_magic), c = e - r * D;
         po[j] = a.obs_raw[(r0 + r) * a.obs_ld + c];
       }
     }
@@ -577,6 +620,27 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
       pw_L[j] = (float)a.ep_len[i];
     }
   }
+  // operands of the state derivation below (one column per thread for the maxima, two for the normaliser)
+  const bool pre_k = K <= kThreads;
+  float pk_m = 0.0f, pk_rm = 0.0f;
+  if (pre_k && threadIdx.x < K) {
+    pk_m = load_colmax(a, threadIdx.x);
+    if (!a.first_call) pk_rm = a.rm[threadIdx.x];
+  }
+  double pn_sx[kMaxObsPerThread], pn_sxx[kMaxObsPerThread];
+  float pn_mean[kMaxObsPerThread], pn_var[kMaxObsPerThread], pn_cnt = 0.0f;
+  if (a.obs_raw != nullptr) {
+    pn_cnt = a.obs_count[0];
+#pragma unroll
+    for (int q = 0; q < kMaxObsPerThread; ++q) {
+      const int c = threadIdx.x + q * kThreads;
+      pn_sx[q] = 0.0, pn_sxx[q] = 0.0, pn_mean[q] = 0.0f, pn_var[q] = 0.0f;
+      if (c < D) {
+        load_sums(a, c, &pn_sx[q], &pn_sxx[q]);
+        pn_mean[q] = a.obs_mean[c], pn_var[q] = a.obs_var[c];
+      }
+    }
+  }
   float pe_reward = 0.0f;
   bool pe_rs = false, pe_to = false;
   if (threadIdx.x < rows) {
@@ -592,21 +656,25 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
   for (int c = threadIdx.x; c < K; c += kThreads) {
     int t = 0;
     while (t + 1 < nt && c >= s_off[t + 1]) ++t;
-    col_rm[c] = derive_running_max(a, c);
+    col_rm[c] = pre_k ? running_max_from(a, pk_m, pk_rm) : derive_running_max(a, c);
     col_dp[c] = meta.dp[t];
   }
   // ---- merged observation normaliser (cleanrl/ppo.py:48-62, the op order of rms.hip)
   if (a.obs_raw != nullptr) {
-    const float cnt = a.obs_count[0];
+    const float cnt = pn_cnt;
     const float nf = (float)a.obs_n;
     const float tot = cnt + nf;
     if (threadIdx.x == 0) s_tot = tot;
-    for (int c = threadIdx.x; c < D; c += kThreads) {
-      float new_mean, new_var;
-      derive_normaliser(a, c, cnt, nf, tot, &new_mean, &new_var);
-      s_mean[c] = new_mean;
-      s_var[c] = new_var;
-      s_den[c] = sqrtf(new_var + a.obs_eps);
+#pragma unroll
+    for (int q = 0; q < kMaxObsPerThread; ++q) {          // D <= kMaxObsPerThread * kThreads (check_step)
+      const int c = threadIdx.x + q * kThreads;
+      if (c < D) {
+        float new_mean, new_var;
+        normaliser_from(a, pn_sx[q], pn_sxx[q], pn_mean[q], pn_var[q], cnt, nf, tot, &new_mean, &new_var);
+        s_mean[c] = new_mean;
+        s_var[c] = new_var;
+        s_den[c] = sqrtf(new_var + a.obs_eps);
+      }
     }
   }
   __syncthreads();
@@ -628,7 +696,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     for (int j = 0; j < kPreC; ++j) {
       const int e = threadIdx.x + j * kThreads;
       if (e < n_el) {
-        const float p = prob_of(pc[j], e % K);
+        const float p = prob_of(pc[j], e - fast_div(e, a.k_magic) * K);
         tile[e] = p;
         if (pdst) pdst[e] = p;
       }
@@ -719,7 +787,7 @@ __global__ __launch_bounds__(kThreads) void rollout_post_kernel(const PostArgs a
     for (int j = 0; j < kPreO; ++j) {
       const int e = threadIdx.x + j * kThreads;
       if (e < rows * D) {
-        const int r = e / D, c = e - r * D;
+        const int r = fast_div(e, a.d_magic), c = e - r * D;
         const float v = po[j] - s_mean[c];
         a.obs_out[(r0 + r) * a.obs_out_ld + c] = v / s_den[c];
       }
@@ -986,6 +1054,7 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   p.reset_part = rpart;
   p.ticket = ctx->tickets + catppo_ctx::kTicketPost;
   p.defer = defer ? 1 : 0;
+  p.d_magic = catppo_div_magic((uint32_t)(D > 0 ? D : 1)), p.k_magic = catppo_div_magic((uint32_t)K);
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_post_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

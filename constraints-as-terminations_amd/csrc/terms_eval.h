@@ -21,6 +21,7 @@ constexpr int kMaxTerms = 16;
 struct TermTable {
   int n;
   int off[kMaxTerms + 1];
+  uint32_t wmagic[kMaxTerms];     // catppo_div_magic(width): (env, column) of a flat index without an integer division
   catppo_term_desc d[kMaxTerms];
 };
 
@@ -133,6 +134,7 @@ inline const char* build_table(const catppo_term_desc* desc, int n_terms, const 
                         d.kind != CATPPO_TERM_LIMIT_MINUS;
     if (!(per_id ? d.width == d.n_ids : d.width == 1)) return "term width does not match its id list";
     tab->off[t] = off;
+    tab->wmagic[t] = catppo_div_magic((uint32_t)d.width);
     tab->d[t] = d;
     off += d.width;
   }

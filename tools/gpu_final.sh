@@ -41,6 +41,15 @@ if [ -f tools/bin/libcatppo_fftl.so ]; then
   echo "== rows_fwd timeline ($(( $(date +%s) - T0 )) s)"
   (CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 48 2; CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 240 2) 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_rows_fwd_timeline.txt"
 fi
+if [ -f tools/bin/libcatppo_tl.so ]; then
+  echo "== rollout timeline ($(( $(date +%s) - T0 )) s)"
+  CATPPO_LIB=$PWD/tools/bin/libcatppo_tl.so timeout 200 python tools/rollout_timeline.py cfg2 2>&1 | grep -v "amdgpu.ids\|^\[INFO\]\|^Index\|^[0-9] |\|Active Constraint\|^$" > "$OUT/${TAG}_rollout_timeline_final.txt"
+fi
+if [ -f tools/bin/libcatppo_r5d.so ]; then
+  echo "== env step: this tree against the build with only the deferred tail ($(( $(date +%s) - T0 )) s)"
+  ROUNDS=3 OUT=$OUT/${TAG}_ab_rollout_trim.jsonl bash tools/gpu_exp.sh "cfg2 deferred_tail_only CATPPO_LIB=$PWD/tools/bin/libcatppo_r5d.so" "cfg2 final X=1" > "$OUT/${TAG}_ab_rollout_trim.txt" 2>&1
+  tail -3 "$OUT/${TAG}_ab_rollout_trim.txt"
+fi
 python - "$OUT" "$TAG" <<'PY'
 import json,sys,os
 out=sys.argv[1]; TAG=sys.argv[2]
