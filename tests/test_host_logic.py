@@ -259,3 +259,39 @@ def test_update_from_moments_matches_the_reference_running_mean_std(golden):
         np.testing.assert_allclose(st, g["vec_state"][i], rtol=1e-6, atol=1e-7)
     np.testing.assert_array_equal(m.numpy(), rms.running_mean.numpy())
     np.testing.assert_array_equal(v.numpy(), rms.running_var.numpy())
+
+
+def test_index_division_magic_is_exact_over_the_whole_index_range(tmp_path):
+    """`catppo_div_magic` / `fast_div` (csrc/common.h, round 5): the env-step kernels divide small indices by run-time widths
+    with one multiply-high; exact only because e * d < 2^32 in every use (e < 2^17 rows x columns, d <= 4096 columns).
+    Checked exhaustively with the library's OWN host function: a host program built from common.h (hipcc compiles host code
+    without a GPU), `(e * magic) >> 32` being what `__umulhi` computes on the device."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = tmp_path / "div_magic.hip"
+    src.write_text(r"""
+#include "common.h"
+#include <cstdio>
+int main() {
+  long bad = 0;
+  for (uint32_t d = 1; d <= 4096; ++d) {
+    const uint32_t m = catppo_div_magic(d);
+    for (uint32_t e = 0; e < (1u << 17); ++e) {
+      const uint32_t q = m ? (uint32_t)(((uint64_t)e * m) >> 32) : e;
+      bad += q != e / d;
+    }
+  }
+  printf("bad %ld\n", bad);
+  return bad != 0;
+}
+""")
+    exe = tmp_path / "div_magic"
+    csrc = os.path.join(ROOT, "constraints-as-terminations_amd", "csrc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", f"-I{csrc}", "-o", str(exe), str(src)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "bad 0", r.stdout + r.stderr
