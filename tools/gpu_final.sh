@@ -7,11 +7,14 @@ OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 T0=$(date +%s)
+# SKIP_TESTS=1: profile passes and bench lines only (a second box for the same, already validated tree)
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
 echo "== GPU suite"
 timeout 1500 python -m pytest tests -m gpu -q --timeout 600 -p no:cacheprovider -x > "$OUT/final_tests.log" 2>&1
 tail -6 "$OUT/final_tests.log" | cut -c1-220
 echo "== smoke ($(( $(date +%s) - T0 )) s)"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+fi
 echo "== profile passes first (the bench line then finds a PMC summary stamped with this tree) ($(( $(date +%s) - T0 )) s)"
 bash tools/profile_bench.sh cfg2 $TAG > "$OUT/final_profile.log" 2>&1
 python tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq1_cfg2.csv" "$OUT/${TAG}_pmc_sq2_cfg2.csv" > "$OUT/${TAG}_pmc_sq_summary_cfg2.json" 2>/dev/null
@@ -37,15 +40,15 @@ timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2> "
 echo "== three more default lines back to back (run-to-run spread) ($(( $(date +%s) - T0 )) s)"
 : > "$OUT/${TAG}_bench_cfg2_repeats.jsonl"
 for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/${TAG}_bench_cfg2_repeats.jsonl"; done
-if [ -f tools/bin/libcatppo_fftl.so ]; then
+if [ "${SKIP_TESTS:-0}" != "1" ] && [ -f tools/bin/libcatppo_fftl.so ]; then
   echo "== rows_fwd timeline ($(( $(date +%s) - T0 )) s)"
   (CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 48 2; CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 240 2) 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_rows_fwd_timeline.txt"
 fi
-if [ -f tools/bin/libcatppo_tl.so ]; then
+if [ "${SKIP_TESTS:-0}" != "1" ] && [ -f tools/bin/libcatppo_tl.so ]; then
   echo "== rollout timeline ($(( $(date +%s) - T0 )) s)"
   CATPPO_LIB=$PWD/tools/bin/libcatppo_tl.so timeout 200 python tools/rollout_timeline.py cfg2 2>&1 | grep -v "amdgpu.ids\|^\[INFO\]\|^Index\|^[0-9] |\|Active Constraint\|^$" > "$OUT/${TAG}_rollout_timeline_final.txt"
 fi
-if [ -f tools/bin/libcatppo_r5d.so ]; then
+if [ "${SKIP_TESTS:-0}" != "1" ] && [ -f tools/bin/libcatppo_r5d.so ]; then
   echo "== env step: this tree against the build with only the deferred tail ($(( $(date +%s) - T0 )) s)"
   ROUNDS=3 OUT=$OUT/${TAG}_ab_rollout_trim.jsonl bash tools/gpu_exp.sh "cfg2 deferred_tail_only CATPPO_LIB=$PWD/tools/bin/libcatppo_r5d.so" "cfg2 final X=1" > "$OUT/${TAG}_ab_rollout_trim.txt" 2>&1
   tail -3 "$OUT/${TAG}_ab_rollout_trim.txt"
