@@ -295,3 +295,72 @@ int main() {
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "bad 0", r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("world", [2, 8, 22, 64])
+def test_native_comm_known_answer_pass_holds_for_any_world_size(world):
+    """`cat_envs.parallel._selfcheck` (the known-answer pass every rank runs on a fresh RCCL communicator before the data
+    path may use it): its closed-form answers must hold for ANY world size - ADVICE r4: the fp64 tolerance once failed from
+    22 ranks on, which would have dropped every multi-node job to the fallback transport.  `world` ranks as threads of this
+    process around an in-memory communicator with RCCL's semantics (SUM in the operand's dtype, MAX, broadcast, all-gather)."""
+    import threading
+    from cat_envs import parallel
+
+    slots, lock, bar = {}, threading.Lock(), threading.Barrier(world)
+
+    class FakeNat:
+        device = torch.device("cpu")
+
+        def __init__(self, r):
+            self.r, self.n = r, 0
+
+        def _exchange(self, t):
+            k = self.n
+            self.n += 1
+            with lock:
+                slots.setdefault(k, {})[self.r] = t.clone()
+            bar.wait()
+            out = [slots[k][q] for q in range(world)]
+            bar.wait()
+            return out
+
+        def allreduce(self, t, op):
+            parts = self._exchange(t)
+            acc = parts[0].clone()
+            for q in parts[1:]:
+                acc = torch.maximum(acc, q) if op == 1 else acc + q
+            t.copy_(acc)
+
+        def broadcast(self, t, src):
+            t.copy_(self._exchange(t)[src])
+
+        def allgather(self, send, recv):
+            recv.copy_(torch.cat(self._exchange(send)))
+
+    res = [None] * world
+
+    def rank_main(r):
+        res[r] = parallel._selfcheck(FakeNat(r), r, world)
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert res == [None] * world, res
+    # and a wrong collective is caught: the same pass around a communicator whose SUM drops the last rank
+    slots.clear()
+
+    class LossyNat(FakeNat):
+        def allreduce(self, t, op):
+            parts = self._exchange(t)
+            acc = parts[0].clone()
+            for q in parts[1:-1] if op == 0 else parts[1:]:
+                acc = torch.maximum(acc, q) if op == 1 else acc + q
+            t.copy_(acc)
+
+    def lossy_main(r):
+        res[r] = parallel._selfcheck(LossyNat(r), r, world)
+
+    th = [threading.Thread(target=lossy_main, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert all(isinstance(x, str) and "SUM fp32" in x and "SUM fp64" in x for x in res), res
