@@ -133,6 +133,7 @@ def init_native_comm(nat, group=None) -> bool:
         _ensure_device_fallback(group)
         return False
     _native = nat
+    _native_error = None                  # (a set-up that succeeds after an earlier failure: the old reason is history)
     return True
 
 

@@ -262,3 +262,97 @@ def test_minibatch_plan_is_identical_on_every_rank_for_ragged_shards():
     assert n_mb == 6 and m_r == [4100, 4096] and glob == [8196] * 6
     with pytest.raises(ValueError):
         parallel.minibatch_plan([59, 58], 2)      # 29 minibatches of ceil(59/29) = 3 rows: rank 0 runs out after 20
+
+
+# ------------------------------------------------------------------ communicator set-up votes (round 5)
+class _FakeNat:
+    """libcatppo's communicator calls as cat_envs.parallel.init_native_comm uses them, over the gloo group itself:
+    `scenario` injects the failure one rank sees"""
+
+    def __init__(self, rank, scenario):
+        self.rank, self.scenario, self.comm_world = rank, scenario, 0
+        self.device = torch.device("cpu")
+        self.inits = self.destroys = 0
+
+    def comm_unique_id(self):
+        return b"u" * 128
+
+    def comm_probe(self):
+        if self.scenario == "probe_fails_on_rank1" and self.rank == 1:
+            raise OSError("librccl.so: cannot open shared object file")
+
+    def comm_init(self, r, w, uid):
+        assert uid == b"u" * 128
+        if self.scenario == "init_fails_on_rank0" and r == 0:
+            raise RuntimeError("libcatppo error -3: ncclCommInitRank: unhandled system error")
+        self.inits += 1
+        self.comm_world = w
+
+    def comm_destroy(self):
+        self.destroys += 1
+        self.comm_world = 0
+
+    def allreduce(self, t, op):
+        if self.scenario == "wrong_sum_on_rank1" and self.rank == 1 and t.dtype == torch.float32 and op == 0:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t += 1.0
+            return
+        if t.dtype == torch.float16:                     # gloo has no fp16 SUM: widen
+            w = t.float()
+            dist.all_reduce(w, op=dist.ReduceOp.SUM)
+            t.copy_(w.half())
+            return
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM)
+
+    def broadcast(self, t, src):
+        dist.broadcast(t, src)
+
+    def allgather(self, send, recv):
+        parts = [torch.empty_like(send) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, send)
+        recv.copy_(torch.cat(parts))
+
+
+def _vote_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "constraints-as-terminations_amd"), HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from cat_envs import parallel
+    parallel.init_rendezvous(None, timeout_s=120)
+    assert dist.get_backend() == "gloo" and parallel.active()
+    done = []
+    for scenario in ("probe_fails_on_rank1", "init_fails_on_rank0", "wrong_sum_on_rank1", "healthy"):
+        nat = _FakeNat(rank, scenario)
+        ok = parallel.init_native_comm(nat)
+        err = parallel.native_comm_error()
+        if scenario == "healthy":
+            assert ok and parallel.native_comm_active() and nat.inits == 1 and nat.destroys == 0
+            assert err is None, err                      # the earlier scenarios' reasons do not stick to a healthy set-up
+            assert parallel.reinit_native_comm() and nat.inits == 2 and nat.destroys == 1     # fresh communicator, both ranks
+            parallel.shutdown_native_comm()
+            assert not parallel.native_comm_active() and nat.destroys == 2
+        else:
+            # EVERY rank ends up on the fallback, with the failing rank named - nobody is left waiting inside the set-up
+            assert not ok and not parallel.native_comm_active() and nat.comm_world == 0, (scenario, ok)
+            want = {"probe_fails_on_rank1": "rank 1: librccl.so", "init_fails_on_rank0": "rank 0: libcatppo error -3",
+                    "wrong_sum_on_rank1": "rank 1: wrong result of SUM fp32"}[scenario]
+            assert err is not None and want in err, (scenario, err)
+            if scenario == "probe_fails_on_rank1":
+                assert nat.inits == 0                    # nobody entered the blocking communicator set-up
+            if scenario == "init_fails_on_rank0":
+                assert nat.destroys == (1 if rank == 1 else 0)      # the rank whose set-up succeeded gives it back
+        done.append(scenario)
+    open(os.path.join(out_dir, f"votes{rank}"), "w").write(",".join(done))
+    dist.destroy_process_group()
+
+
+def test_communicator_setup_votes_keep_every_rank_on_one_transport_world2_gloo(tmp_path):
+    """cat_envs.parallel.init_native_comm (VERDICT r4 item 4 / ADVICE r4): a failure that only ONE rank sees - librccl not
+    loadable, ncclCommInitRank failing, a wrong known-answer result - must leave BOTH ranks on the fallback transport with
+    the failing rank named, and never one rank inside the blocking set-up waiting for the other; a healthy set-up is kept,
+    can be re-created collectively (after an aborted graph capture) and torn down.  Two real processes on gloo."""
+    port = _free_port()
+    mp.spawn(_vote_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"votes{r}").read() == "probe_fails_on_rank1,init_fails_on_rank0,wrong_sum_on_rank1,healthy"
