@@ -13,6 +13,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "constraints-as-terminations_amd"))
 import bench  # noqa: E402
 
 
@@ -32,6 +33,12 @@ def run(workload, iters, defer):
 
 
 def main():
+    if os.environ.get("CATPPO_FORCE_DIST") == "1":      # every exchange point on over a world of one (gathered records)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+        from cat_envs import parallel
+        parallel.init_rendezvous(0)
     wl = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     import contextlib
@@ -40,7 +47,8 @@ def main():
         b = run(wl, iters, True)
     bad = [k for k in a if a[k] != b[k]]
     T = bench.WORKLOADS[wl]["num_steps"]
-    print(f"{wl}: {iters} iterations = {iters * T} env steps per mode; digests", "EQUAL" if not bad else f"DIFFER in {bad}")
+    mode = "every exchange point forced on (world of one), " if os.environ.get("CATPPO_FORCE_DIST") == "1" else ""
+    print(f"{wl}: {mode}{iters} iterations = {iters * T} env steps per mode; digests", "EQUAL" if not bad else f"DIFFER in {bad}")
     for k in a:
         print(f"  {k:8s} {a[k]} {b[k]}")
     return 1 if bad else 0
