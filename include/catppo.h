@@ -568,7 +568,9 @@ int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* str
  * valid after catppo_rollout_post as before.  Values are bit-identical either way: the tail derives the state with the same
  * device functions from the same exchange record(s) - which must stay untouched until then (they are: the next writer is
  * the fold behind the next catppo_rollout_pre / the next all-gather).  The rollout loop of cleanrl/ppo.py's PPOTrainer
- * switches it on around its env steps and off (= flush) before GAE.  Reference: the statistics concerned are
+ * switches it on around its env steps and off (= flush) before GAE.  One stream per context while it is on: the pending
+ * tail and its reset-statistics rows belong to the context, and a post call on ANOTHER stream is ordered behind the tail's
+ * launch only by the caller.  Reference: the statistics concerned are
  * ConstraintManager's running maxima (cat/constraint_manager.py:58-61), RunningMeanStd's state (cleanrl/ppo.py:48-62)
  * and the episode log of ConstraintManager.reset (cat/constraint_manager.py:190-211). */
 int catppo_rollout_defer_tail(catppo_ctx* ctx, int on, void* stream);
