@@ -26,6 +26,7 @@ namespace {
 #include "mlp_common.h"
 #include "mlp_forward.h"
 #include "mlp_loss.h"
+#include "step16.h"
 #include "mlp_backward.h"
 #include "mlp_optim.h"
 
@@ -512,7 +513,62 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const int RB = (int)cdiv64(M, 64);
   const bool fused_head = fused_head_env && (HL == 128 || HL == 256) && nl >= 2 &&
                           L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= fused_head_min && A <= 15;
-  if (fused_head) {
+  // Round 6: small minibatches (an env-sharded rank's 2048 rows, cfg1) - forward, heads, loss, head backward and the data
+  // gradients of the hidden layers in ONE launch of 16-row workgroups (step16.h), then every layer's weight gradient in
+  // one grouped launch (dw_multi_kernel) and the fold: 3 launches instead of 10.  CATPPO_STEP16=0 keeps the layer-wise
+  // launches (A/B), CATPPO_STEP16_MAX_ROWS moves the upper bound of the window.
+  bool step16_done = false;
+  {
+    static const int s16_on = env_int("CATPPO_STEP16", 1);
+    static const int s16_max = env_int("CATPPO_STEP16_MAX_ROWS", 4096);
+    const bool plain = !ctx->use_side && !(ctx->grad_overlap == 1 && ctx->comm != nullptr);
+    if (s16_on && plain && M <= s16_max && shape->mfma_bf16 == 0 && nl == 3 && A <= 15 && M * 512 * 4 < (int64_t(1) << 31)) {
+      step16::Args sa{};
+      sa.x = w.xmb, sa.params = params, sa.M = M;
+      for (int net = 0; net < 2; ++net) {
+        for (int l = 0; l <= nl; ++l) sa.off_w[net][l] = L.off_w[net][l], sa.off_b[net][l] = L.off_b[net][l];
+        for (int l = 0; l < nl; ++l) sa.H[net][l] = l + 1 < nl ? w.H[net][l] : nullptr, sa.dZ[net][l] = w.dZ[net][l];
+      }
+      HeadArgs& g = sa.g;
+      g.W4c = params + L.off_w[0][nl], g.b4c = params + L.off_b[0][nl];
+      g.W4a = params + L.off_w[1][nl], g.b4a = params + L.off_b[1][nl];
+      g.logstd = params + L.off_logstd;
+      g.act = w.act, g.oldlogp = w.scal, g.adv = w.scal + M, g.ret_n = w.scal + 2 * M, g.val_n = w.scal + 3 * M;
+      g.adv_part = w.adv_part, g.n_adv_part = nbg;
+      g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
+      g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
+      g.part_w = w.head_w, g.part_s = w.head_s;
+      g.M = M, g.A = A, g.hp = *hp;
+      const int tiles16 = (int)cdiv64(M, step16::kR);
+      auto launch16 = [&](auto dp, auto n0, auto n1, auto n2) {
+        constexpr int DP = decltype(dp)::value, N0 = decltype(n0)::value, N1 = decltype(n1)::value, N2 = decltype(n2)::value;
+        constexpr size_t lds = sizeof(float) * step16::lds_floats<DP, N0, N1, N2>();
+        auto kern = step16_kernel<DP, N0, N1, N2>;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles16, 2), dim3(step16::kThreads), lds, s, sa);
+        step16_done = true;
+      };
+      using std::integral_constant;
+      const int h0 = shape->hidden[0], h1 = shape->hidden[1], h2 = shape->hidden[2];
+#define CATPPO_S16(DP_, A_, B_, C_)                                                                          \
+      if (!step16_done && L.obs_pad == DP_ && h0 == A_ && h1 == B_ && h2 == C_)                               \
+        launch16(integral_constant<int, DP_>{}, integral_constant<int, A_>{}, integral_constant<int, B_>{},  \
+                 integral_constant<int, C_>{});
+      CATPPO_S16(48, 512, 256, 128)      // the reference's Agent (45 / 48-d observations): cfg1, cfg3
+      CATPPO_S16(48, 256, 256, 256)      // BASELINE configs[1]
+#undef CATPPO_S16
+      if (step16_done) {
+        catppo_plan_note(ctx, "minibatch %lld rows: step16_kernel<%d, %d, %d, %d> - forward, heads, PPO loss, head backward and the "
+                         "hidden layers' data gradients in ONE launch, %d tiles of 16 rows x 2 networks [<= %d rows, fp32, "
+                         "a compiled shape]", (long long)M, L.obs_pad, h0, h1, h2, tiles16, s16_max);
+        CATPPO_CHECK_LAUNCH(ctx);
+        nbh = tiles16;
+      }
+    }
+  }
+  if (step16_done) {
+  } else if (fused_head) {
     // hidden layers below the last: ONE row-resident launch (fwd_rows.h) when they are all 256 wide and the minibatch has
     // enough 64-row tiles, else the layer-wise GEMM launches.  CATPPO_ROWS_FWD=0 keeps the latter (A/B).
     static const int rows_fwd_env = env_int("CATPPO_ROWS_FWD", 1);
@@ -671,14 +727,9 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     if (e__ != hipSuccess)                                                                           \
       return catppo_fail(ctx, CATPPO_E_HIP, "%s: %s failed: %s", __func__, #call, hipGetErrorString(e__)); \
   } while (0)
-  for (int l = nl - 1; l >= 0; --l) {
+  // split-K weight-gradient problem of hidden layer l (tiling rule shared by every backward path)
+  auto dw_params = [&](int l) {
     const int out = shape->hidden[l], in = L.in_dim[l];
-    // dZ_l is complete on the main stream here: fork
-    if (fork) {
-      CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
-      CATPPO_HIP_OK(hipStreamWaitEvent(side, ctx->ev_fork[l], 0));
-    }
-    // weight gradient: dW[out,in] = dZ^T . Xin      (contraction over the M rows)
     Params pw{};
     pw.xcd_legacy = xcd_legacy();
     pw.nets = 2;
@@ -715,6 +766,65 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       pw.op[net].C = w.wpart[l] + (int64_t)net * out * in;
       pw.op[net].dbias = w.bpart[l] + (int64_t)net * splits * out;   // [net][split][out]
     }
+    return pw;
+  };
+  const bool head_by_net = fused_head || step16_done;     // head partial rows [0, nbh) actor, [nbh, 2 nbh) critic
+  auto add_head_segs = [&]() {
+    // head partials + diagnostics ride along with the reduction launch
+    const int NS = head_scalars(A);
+    const int64_t wrow = (int64_t)(A + 1) * HL;
+    const float* cw = w.head_w + (head_by_net ? (int64_t)nbh * wrow : 0);
+    const float* cs = w.head_s + (head_by_net ? (int64_t)nbh * NS : 0);
+    add_seg(w.head_w, grad + L.off_w[1][nl], (int64_t)A * HL, wrow, nbh, 0, 1.0f);
+    add_seg(cw + (int64_t)A * HL, grad + L.off_w[0][nl], HL, wrow, nbh, 0, 1.0f);
+    add_seg(w.head_s, grad + L.off_b[1][nl], A, NS, nbh, 0, 1.0f);
+    add_seg(cs + A, grad + L.off_b[0][nl], 1, NS, nbh, 0, 1.0f);
+    add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
+    add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, head_by_net ? 2 * nbh : nbh, 1, hp->inv_global_batch);
+  };
+  if (step16_done) {
+    // every dZ is in memory: all weight gradients in ONE grouped launch of 64x64-tile split-K workgroups, the layer with
+    // the longest contraction chunks first
+    DwMulti dm{};
+    int order[CATPPO_MAX_HIDDEN];
+    for (int l = 0; l < nl; ++l) order[l] = l;
+    Params pws[CATPPO_MAX_HIDDEN];
+    for (int l = 0; l < nl; ++l) pws[l] = dw_params(l);
+    for (int i = 0; i < nl; ++i)
+      for (int j = i + 1; j < nl; ++j)
+        if (pws[order[j]].kc_per_split > pws[order[i]].kc_per_split) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    int total = 0;
+    for (int i = 0; i < nl; ++i) {
+      const Params& pw = pws[order[i]];
+      dm.p[i] = pw;
+      dm.tiles[i] = tiles_of<64, 64>(pw);
+      dm.first[i] = total;
+      total += dm.tiles[i] * pw.nets * pw.splits;
+    }
+    dm.first[nl] = total, dm.n = nl;
+    constexpr size_t dw_lds = gemm::smem_bytes<64, 64, false, false>();
+    hipLaunchKernelGGL(dw_multi_kernel, dim3((unsigned)total), dim3(256), dw_lds, s, dm);
+    catppo_plan_note(ctx, "weight gradients of all %d hidden layers: dw_multi_kernel, %d workgroups of 64x64 split-K tiles, ONE launch", nl, total);
+    CATPPO_CHECK_LAUNCH(ctx);
+    for (int l = nl - 1; l >= 0; --l) {
+      const int out = shape->hidden[l], in = L.in_dim[l], splits = pws[l].splits;
+      for (int net = 0; net < 2; ++net) {
+        add_seg(w.wpart[l] + (int64_t)net * out * in, grad + L.off_w[net][l], (int64_t)out * in, 2 * (int64_t)out * in, splits, 0, 1.0f);
+        add_seg(w.bpart[l] + (int64_t)net * splits * out, grad + L.off_b[net][l], out, out, splits, 0, 1.0f);
+      }
+      if (l == nl - 1) add_head_segs();
+    }
+  }
+  for (int l = step16_done ? -1 : nl - 1; l >= 0; --l) {
+    const int out = shape->hidden[l], in = L.in_dim[l];
+    // dZ_l is complete on the main stream here: fork
+    if (fork) {
+      CATPPO_HIP_OK(hipEventRecord(ctx->ev_fork[l], s));
+      CATPPO_HIP_OK(hipStreamWaitEvent(side, ctx->ev_fork[l], 0));
+    }
+    // weight gradient: dW[out,in] = dZ^T . Xin      (contraction over the M rows)
+    const Params pw = dw_params(l);
+    const int splits = pw.splits, per = pw.kc_per_split;
     static const bool no_pair = getenv("CATPPO_NO_PAIR") != nullptr;
     const bool pair = l > 0 && !fork && !no_pair;
     // (round 4, measured and removed: a 256 x 64 tile for the narrow first layer - one workgroup per CU owning all 256
@@ -768,20 +878,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
               2 * (int64_t)out * in, splits, 0, 1.0f);
       add_seg(w.bpart[l] + (int64_t)net * splits * out, grad + L.off_b[net][l], out, out, splits, 0, 1.0f);
     }
-    if (l == nl - 1) {
-      // head partials + diagnostics ride along with the reduction launch
-      const int NS = head_scalars(A);
-      // fused head: partial rows [0, nbh) come from the actor workgroups, [nbh, 2 nbh) from the critic's
-      const int64_t wrow = (int64_t)(A + 1) * HL;
-      const float* cw = w.head_w + (fused_head ? (int64_t)nbh * wrow : 0);
-      const float* cs = w.head_s + (fused_head ? (int64_t)nbh * NS : 0);
-      add_seg(w.head_w, grad + L.off_w[1][nl], (int64_t)A * HL, wrow, nbh, 0, 1.0f);
-      add_seg(cw + (int64_t)A * HL, grad + L.off_w[0][nl], HL, wrow, nbh, 0, 1.0f);
-      add_seg(w.head_s, grad + L.off_b[1][nl], A, NS, nbh, 0, 1.0f);
-      add_seg(cs + A, grad + L.off_b[0][nl], 1, NS, nbh, 0, 1.0f);
-      add_seg(w.head_s + A + 1, grad + L.off_logstd, A, NS, nbh, 0, 1.0f);
-      add_seg(w.head_s + 2 * A + 1, diag, kHeadDiag, NS, fused_head ? 2 * nbh : nbh, 1, hp->inv_global_batch);
-    }
+    if (l == nl - 1) add_head_segs();
     if (l > 0) {
       // data gradient: dZ_{l-1} = (dZ_l . W_l) * elu'(H_{l-1})
       Params px{};

@@ -181,3 +181,22 @@ __global__ __launch_bounds__(256) void dw_fold_kernel(const gemm::Params p, cons
     if (norm_slots != nullptr) emit_norm_slot(ss, norm_slots + f, smem);
   }
 }
+
+// Every hidden layer's split-K weight gradient in ONE launch (round 6, the small-minibatch step of step16.h: all dZ are in
+// memory when the backward chain's launch ends, so nothing orders the weight gradients against each other).  All
+// problems use gemm_body's 64x64 EPI_PARTIAL tile - one instruction stream, the problem picked by workgroup index; the
+// partial sums per element are those of the per-layer launches (same splits, same slab order).
+struct DwMulti {
+  gemm::Params p[CATPPO_MAX_HIDDEN];
+  int first[CATPPO_MAX_HIDDEN + 1];    // first workgroup of problem i (launch order); first[n] = grid size
+  int tiles[CATPPO_MAX_HIDDEN];        // 64x64 tiles of one (network, split) slice
+  int n;
+};
+__global__ __launch_bounds__(256) void dw_multi_kernel(const DwMulti m) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  int i = 0;
+  while (i + 1 < m.n && b >= m.first[i + 1]) ++i;
+  const gemm::TileId id = gemm::xcd_tile_of(b - m.first[i], m.tiles[i], (m.first[i + 1] - m.first[i]) / m.tiles[i], m.p[i].xcd_legacy);
+  gemm::gemm_body<64, 64, false, false, gemm::EPI_PARTIAL>(m.p[i], id.tile, id.bz, smem);
+}

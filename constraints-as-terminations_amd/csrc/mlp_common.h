@@ -92,7 +92,8 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
     return p;
   };
   const int nl = s->n_hidden, A = s->act_dim;
-  const int64_t nbg = cdiv64(M, kGatherRows), nbh = cdiv64(M, 16);   // upper bound of head_loss blocks
+  // upper bound of the head partial rows: head_loss blocks (16-row tiles at most), or step16's 16-row tiles x 2 networks
+  const int64_t nbg = cdiv64(M, kGatherRows), nbh = M <= 8192 ? 2 * cdiv64(M, 16) : cdiv64(M, 16);
   // reduction partials first: the non-MLP calls use the front of the workspace too, but never
   // concurrently with an MLP call on the same stream
   w->xmb = (float*)take(sizeof(float) * M * L.obs_pad);
