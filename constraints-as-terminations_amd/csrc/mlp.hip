@@ -524,7 +524,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     const bool plain = !ctx->use_side && !(ctx->grad_overlap == 1 && ctx->comm != nullptr);
     if (s16_on && plain && M <= s16_max && shape->mfma_bf16 == 0 && nl == 3 && A <= 15 && M * 512 * 4 < (int64_t(1) << 31)) {
       step16::Args sa{};
-      sa.x = w.xmb, sa.params = params, sa.M = M;
+      sa.x = w.xmb, sa.params = params, sa.M = M, sa.n_flat = L.n_flat;
       for (int net = 0; net < 2; ++net) {
         for (int l = 0; l <= nl; ++l) sa.off_w[net][l] = L.off_w[net][l], sa.off_b[net][l] = L.off_b[net][l];
         for (int l = 0; l < nl; ++l) sa.H[net][l] = l + 1 < nl ? w.H[net][l] : nullptr, sa.dZ[net][l] = w.dZ[net][l];
@@ -1051,6 +1051,13 @@ extern "C" int catppo_ppo_minibatch_step_packed(catppo_ctx* ctx, const catppo_ml
   CATPPO_CHECK_LAUNCH(ctx);
   return CATPPO_OK;
 }
+
+#ifdef STEP16_TL
+extern "C" int catppo_debug_step16_tl(void* buf) {     // timeline builds only: not part of include/catppo.h
+  unsigned long long* pbuf = static_cast<unsigned long long*>(buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(step16::g_s16tl), &pbuf, sizeof(pbuf)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef FUSED_TL
 // timeline builds only (tools/rows_fwd_timeline.py): the training launch of rows_fwd_kernel on its own

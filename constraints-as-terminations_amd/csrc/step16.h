@@ -16,7 +16,7 @@
 //
 // No weight ring in LDS.  A 16 x 16 accumulator tile is 4 VGPRs, so the registers the 32-row kernels spend on
 // accumulators hold the weight stream instead: every lane requests its operand rows straight from global memory (L2
-// hits: all CUs walk the same 1.5 MB), kD 16-k units ahead.
+// hits: all CUs walk the same 1.5 MB), STEP16_DEPTH_KB of weights per wave ahead of their use.
 //   forward (W[n][k], k contiguous):  wave w owns columns [w CW, w CW + CW), CW = N / 8 = 16 T, interleaved over its T
 //       tiles - column of (tile t, c16) = w CW + c16 T + t - so a lane's T outputs of a row are T consecutive floats
 //       (one LDS write, one global store) and its T weight rows are consecutive rows of W;
@@ -42,15 +42,20 @@ using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 constexpr int kThreads = 512;      // eight waves, two per SIMD
 constexpr int kR = 16;             // rows per workgroup
 constexpr int kPad = 8;            // tile row stride = width + 8 floats: the b128 lane groups of gfx950 hit 16 distinct 4-bank slots
-#ifndef STEP16_DEPTH
-#define STEP16_DEPTH 8
+#ifndef STEP16_DEPTH_KB
+#define STEP16_DEPTH_KB 16
 #endif
-constexpr int kD = STEP16_DEPTH;   // weight prefetch depth in 16-k units
+constexpr int kDepthKB = STEP16_DEPTH_KB;   // weight bytes a wave keeps in flight (KB; 64 lanes x 4 B: 4 VGPRs per KB)
+constexpr int depth_of(int elem_kb, int n_elem) {   // pipeline elements of elem_kb KB each
+  int d = kDepthKB / elem_kb;
+  d = d < 2 ? 2 : d;
+  return d < n_elem ? d : n_elem;
+}
 
 struct Args {
   const float* x;                  // [M, Dp] gathered observations
   const float* params;
-  int64_t M;
+  int64_t M, n_flat;
   int64_t off_w[2][CATPPO_MAX_HIDDEN + 1], off_b[2][CATPPO_MAX_HIDDEN + 1];
   float* H[2][CATPPO_MAX_HIDDEN];  // [net][layer] activations out (layers below the last)
   float* dZ[2][CATPPO_MAX_HIDDEN]; // [net][layer] pre-activation gradients out
@@ -73,6 +78,16 @@ __device__ __forceinline__ void vset(typename VecOf<T>::type& v, int t, float x)
   else v[t] = x;
 }
 
+// load T consecutive floats: descriptor (SGPRs) + per-lane byte offset (ONE VGPR per layer) + wave-uniform byte offset (an
+// SGPR add per request).  With plain pointers every request of the unrolled contractions got its own 64-bit VGPR address
+// (row offsets of 2 KB and more do not fit the instruction's immediate): ~40 live pointer pairs, 256 VGPRs and spills.
+template <int T>
+__device__ __forceinline__ typename VecOf<T>::type bload(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff) {
+  if constexpr (T == 4) return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+  else if constexpr (T == 2) return __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+  else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+
 // store T consecutive floats through a buffer descriptor (a row past M: dropped), write-through
 template <int T>
 __device__ __forceinline__ void bstore(const typename VecOf<T>::type& v, __amdgpu_buffer_rsrc_t rs, uint32_t off) {
@@ -93,43 +108,189 @@ __device__ __forceinline__ void prep(const f4v v, float (&o)[4]) {
 // first k row (inside a unit) lane group g4 supplies for operand i of an I-contiguous operand: same order as prep()
 __device__ __forceinline__ int krow_of(int i, int g4) { return 8 * (i >> 1) + 2 * (i & 1) + (g4 >> 1) + 4 * (g4 & 1); }
 
+#ifdef STEP16_TL   // tools/step16_timeline.py: thread 0 of every workgroup stamps the 100 MHz wall clock at the phase boundaries
+__device__ unsigned long long* g_s16tl;    // [2 networks][4096 tiles][16 stamps]
+#define S16_TL(i) do { if (threadIdx.x == 0 && g_s16tl) g_s16tl[(blockIdx.y * 4096 + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define S16_TL(i) do { } while (0)
+#endif
+
 #define STEP16_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
 
-// ---- forward layer: acc[t] (16 rows x 16 columns) = tile[:, :K] . W[w CW + c16 T + t, :K]^T
+// Weight streams.  Every layer object owns a register ring of DE pipeline elements (Fwd16 / Bwd: one 16-k unit; Fwd32: one
+// 32-k stage) requested DE elements ahead of their use.  run() keeps the stream going ACROSS the layer boundary: once
+// its own elements are all requested, every freed slot-time requests an element of the NEXT layer's ring (the rings are
+// separate register arrays; what is live at any time is ~one ring), so the memory pipe neither idles through a layer's
+// tail nor takes the next layer's first DE elements as one burst in front of a barrier.
+struct NoNext {
+  static constexpr int NE = 0, DE = 0;
+  __device__ __forceinline__ void request(int, int) {}
+};
+// what a layer does behind the MFMAs of its element j
+template <class Self, class Next>
+__device__ __forceinline__ void stream_next(Self& me, Next& nx, int j) {
+  if (j + Self::DE < Self::NE) {
+    me.request(j + Self::DE, j % Self::DE);
+  } else {
+    const int idx = j + Self::DE - Self::NE;
+    if (idx < Next::DE) nx.request(idx, idx);
+  }
+  __builtin_amdgcn_sched_barrier(0);        // end of the element's scheduling region
+}
+template <class Self, class Next>
+__device__ __forceinline__ void stream_rest(Next& nx) {      // behind the last element: what the tail could not request
+#pragma unroll
+  for (int idx = Self::DE < Self::NE ? Self::DE : Self::NE; idx < Next::DE; ++idx) nx.request(idx, idx);
+}
+
+// ---- forward layer, 16-k units (any K % 16 == 0; the first layer): acc[t] = tile[:, :K] . W[w CW + c16 T + t, :K]^T
 template <int T, int K>
-struct Fwd {
-  static constexpr int NU = K / 16;
-  static constexpr int D = NU < kD ? NU : kD;
-  static_assert(K % 16 == 0 && NU >= 1, "contraction in 16-k units");
-  f4v ring[D][T];
-  const float* gp;
+struct Fwd16 {
+  static constexpr int NE = K / 16;
+  static constexpr int DE = depth_of(T, NE);
+  static_assert(K % 16 == 0 && NE >= 1, "contraction in 16-k units");
+  f4v ring[DE][T];
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t vo, so;                 // byte offsets into the flat parameter buffer: per lane | of this wave's first weight row
+  __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t prs, int64_t w_off, int wave, int lane) {
+    rs = prs;
+    so = (uint32_t)(w_off + (int64_t)wave * 16 * T * K) * 4u;
+    vo = (uint32_t)(((lane & 15) * T) * K + 4 * (lane >> 4)) * 4u;
+  }
   __device__ __forceinline__ void request(int j, int slot) {
 #pragma unroll
-    for (int t = 0; t < T; ++t) ring[slot][t] = *reinterpret_cast<const f4v*>(gp + t * K + 16 * j);
+    for (int t = 0; t < T; ++t) ring[slot][t] = bload<4>(rs, vo, so + (uint32_t)(t * K + 16 * j) * 4u);
   }
-  __device__ __forceinline__ void prefetch(const float* W, int wave, int lane) {
-    gp = W + (int64_t)(wave * 16 * T + (lane & 15) * T) * K + 4 * (lane >> 4);
+  __device__ __forceinline__ void prefetch() {
 #pragma unroll
-    for (int j = 0; j < D; ++j) request(j, j);
+    for (int j = 0; j < DE; ++j) request(j, j);
   }
-  __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane) {
+  // Every element is one scheduling region (sched_barrier at its end): the MFMAs of element j, the operand preparation of
+  // element j + 1 (LDS read, lane swaps: they issue behind the MFMAs) and one request.  Without the region boundaries the
+  // compiler hoists the LDS reads and swaps of ALL elements of the unrolled contraction to its top (128+ VGPRs of
+  // fragments, spills).
+  template <class Next>
+  __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane, Next& nx) {
     const float* ap = tile + (lane & 15) * ld + 4 * (lane >> 4);
-    f4v af = *reinterpret_cast<const f4v*>(ap);
+    float a[2][4], b[2][T][4];
+    prep(*reinterpret_cast<const f4v*>(ap), a[0]);
+#pragma unroll
+    for (int t = 0; t < T; ++t) prep(ring[0][t], b[0][t]);
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      float a[4], b[T][4];
-      prep(af, a);
-      if (j + 1 < NU) af = *reinterpret_cast<const f4v*>(ap + 16 * (j + 1));
-#pragma unroll
-      for (int t = 0; t < T; ++t) prep(ring[j % D][t], b[t]);
+    for (int j = 0; j < NE; ++j) {
+      const int c = j & 1, n = c ^ 1;
+      f4v af;
+      if (j + 1 < NE) af = *reinterpret_cast<const f4v*>(ap + 16 * (j + 1));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < T; ++t) STEP16_MFMA(a[i], b[t][i], acc[t]);
-      if (j + D < NU) request(j + D, j % D);
+        for (int t = 0; t < T; ++t) STEP16_MFMA(a[c][i], b[c][t][i], acc[t]);
+      if (j + 1 < NE) {
+        prep(af, a[n]);
+#pragma unroll
+        for (int t = 0; t < T; ++t) prep(ring[(j + 1) % DE][t], b[n][t]);
+      }
+      stream_next(*this, nx, j);
     }
+    stream_rest<Fwd16, Next>(nx);
+  }
+};
+
+// ---- forward layer, 32-k stages through a wave-private LDS slot (K % 32 == 0, T = 1 | 2).
+// Fwd16's requests follow the MFMA operand layout: the 16 lanes of a quarter wave address 16 DIFFERENT weight rows, and
+// the texture addresser looks up one 128-byte line per distinct row and quarter wave - 64 look-ups per 1 KB instruction
+// where a coalesced one needs 8.  Measured (profiles/r6_step16_timeline.txt): the 512-k layer took 13-16 us against
+// 8.2 us for the same bytes and MFMA count in the data gradient (whose requests are 256 contiguous bytes per quarter wave);
+// ~1 look-up per clock and CU fits every layer's time.  So the weights are REQUESTED coalesced - lane -> (row lane / 8 +
+// 8 i, 16-byte chunk lane % 8): eight lanes per 128-byte row segment, as fwd_rows.h - parked in registers DE stages
+// ahead, and pass through ONE LDS slot per wave ([16 T rows][32 k + pad]) one stage ahead of their use: ds_write_b128 in
+// the request layout, ds_read_b128 in the operand layout (row c16 T + t, k = 16 u + 4 g4 ..), prep() as for Fwd16.
+// The slot belongs to one wave (LDS operations of a wave execute in order): no barrier.  Row stride S: T S = 8 mod 64
+// floats, the operand reads of a b128 lane group then hit 16 distinct 4-bank slots (as the activation tiles).
+template <int T, int K>
+struct FwdL {
+  static_assert(T == 1 || T == 2, "row stride rule");
+  static constexpr int NE = K / 32;
+  static constexpr int DE = depth_of(2 * T, NE);
+  static constexpr int S = T == 2 ? 36 : 40;
+  static constexpr int NLD = 2 * T;                  // requests per stage: 16 T rows / 8 rows per request
+  static constexpr int kSlotFloats = 16 * T * S;
+  static_assert(K % 32 == 0 && NE >= 1, "contraction in 32-k stages");
+  f4v ring[DE][NLD];
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t vo, so;
+  float* wr;                       // this lane's write position in the slot (row lane / 8, chunk lane % 8)
+  const float* rd;                 // this lane's operand position (row c16 T, k = 4 g4)
+  __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t prs, int64_t w_off, int wave, int lane, float* slot) {
+    rs = prs;
+    so = (uint32_t)(w_off + (int64_t)wave * 16 * T * K) * 4u;
+    vo = (uint32_t)((lane >> 3) * K + 4 * (lane & 7)) * 4u;
+    wr = slot + (lane >> 3) * S + 4 * (lane & 7);
+    rd = slot + (lane & 15) * T * S + 4 * (lane >> 4);
+  }
+  __device__ __forceinline__ void request(int j, int slot) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) ring[slot][i] = bload<4>(rs, vo, so + (uint32_t)(8 * i * K + 32 * j) * 4u);
+  }
+  __device__ __forceinline__ void prefetch() {
+#pragma unroll
+    for (int j = 0; j < DE; ++j) request(j, j);
+  }
+  struct Raw {
+    f4v a[2], b[2][T];
+  };
+  struct Ops {
+    float a[2][4], b[2][T][4];
+  };
+  // stage j: registers -> slot -> operand fragments (+ the activation fragments of the stage)
+  __device__ __forceinline__ void stage_in(Raw& r, const float* __restrict__ ap, int j) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f4v*>(wr + 8 * i * S) = ring[j % DE][i];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      r.a[u] = *reinterpret_cast<const f4v*>(ap + 32 * j + 16 * u);
+#pragma unroll
+      for (int t = 0; t < T; ++t) r.b[u][t] = *reinterpret_cast<const f4v*>(rd + t * S + 16 * u);
+    }
+  }
+  static __device__ __forceinline__ void make_ops(Ops& o, const Raw& r) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      prep(r.a[u], o.a[u]);
+#pragma unroll
+      for (int t = 0; t < T; ++t) prep(r.b[u][t], o.b[u][t]);
+    }
+  }
+  template <class Next>
+  __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane, Next& nx) {
+    const float* ap = tile + (lane & 15) * ld + 4 * (lane >> 4);
+    Ops ops[2];
+    {
+      Raw r;
+      stage_in(r, ap, 0);
+      make_ops(ops[0], r);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {                      // one scheduling region per stage, see Fwd16::run
+      const int c = j & 1, n = c ^ 1;
+      Raw r;
+      if (j + 1 < NE) stage_in(r, ap, j + 1);           // (every fragment of stage j was read in the previous region)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < T; ++t) STEP16_MFMA(ops[c].a[u][i], ops[c].b[u][t][i], acc[t]);
+      if (j + 1 < NE) make_ops(ops[n], r);
+      stream_next(*this, nx, j);
+    }
+    stream_rest<FwdL, Next>(nx);
   }
 };
 
@@ -137,42 +298,58 @@ struct Fwd {
 template <int T, int K, int N>
 struct Bwd {
   using V = typename VecOf<T>::type;
-  static constexpr int NU = K / 16;
-  static constexpr int D = NU < kD ? NU : kD;
-  V ring[D][4];
-  const float* gp;
+  static constexpr int NE = K / 16;
+  static constexpr int DE = depth_of(T, NE);
+  V ring[DE][4];
+  __amdgpu_buffer_rsrc_t rs;
+  uint32_t vo, so;
+  __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t prs, int64_t w_off, int wave, int lane) {
+    rs = prs;
+    so = (uint32_t)(w_off + wave * 16 * T) * 4u;
+    vo = (uint32_t)(krow_of(0, lane >> 4) * N + (lane & 15) * T) * 4u;
+  }
   __device__ __forceinline__ void request(int j, int slot) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      ring[slot][i] = *reinterpret_cast<const V*>(gp + (int64_t)(16 * j + 8 * (i >> 1) + 2 * (i & 1)) * N);
+      ring[slot][i] = bload<T>(rs, vo, so + (uint32_t)((16 * j + 8 * (i >> 1) + 2 * (i & 1)) * N) * 4u);
   }
-  __device__ __forceinline__ void prefetch(const float* W, int wave, int lane) {
-    gp = W + (int64_t)krow_of(0, lane >> 4) * N + wave * 16 * T + (lane & 15) * T;
+  __device__ __forceinline__ void prefetch() {
 #pragma unroll
-    for (int j = 0; j < D; ++j) request(j, j);
+    for (int j = 0; j < DE; ++j) request(j, j);
   }
-  __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane) {
+  template <class Next>
+  __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane, Next& nx) {
     const float* ap = tile + (lane & 15) * ld + 4 * (lane >> 4);
-    f4v af = *reinterpret_cast<const f4v*>(ap);
+    float a[2][4];
+    prep(*reinterpret_cast<const f4v*>(ap), a[0]);
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      float a[4];
-      prep(af, a);
-      if (j + 1 < NU) af = *reinterpret_cast<const f4v*>(ap + 16 * (j + 1));
+    for (int j = 0; j < NE; ++j) {                      // one scheduling region per unit, see Fwd16::run
+      const int c = j & 1, n = c ^ 1;
+      f4v af;
+      if (j + 1 < NE) af = *reinterpret_cast<const f4v*>(ap + 16 * (j + 1));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int t = 0; t < T; ++t) STEP16_MFMA(a[i], vget<T>(ring[j % D][i], t), acc[t]);
-      if (j + D < NU) request(j + D, j % D);
+        for (int t = 0; t < T; ++t) STEP16_MFMA(a[c][i], vget<T>(ring[j % DE][i], t), acc[t]);
+      if (j + 1 < NE) prep(af, a[n]);
+      stream_next(*this, nx, j);
     }
+    stream_rest<Bwd, Next>(nx);
   }
 };
 
+template <int N1, int N2>
+constexpr int slot_floats() {      // one weight slot per wave, shared by the two LDS-staged layers
+  constexpr int s1 = FwdL<N1 / 128, 32>::kSlotFloats, s2 = FwdL<N2 / 128, 32>::kSlotFloats;
+  return s1 > s2 ? s1 : s2;
+}
 template <int DP, int N0, int N1, int N2>
 constexpr size_t lds_floats() {
-  return (size_t)kR * ((DP + kPad) + (N0 + kPad) + (N1 + kPad) + (N2 + kPad)) + 16 * 16 + 16 * 16 + 16 * 8 + 4;
+  return (size_t)kR * ((DP + kPad) + (N0 + kPad) + (N1 + kPad) + (N2 + kPad)) + 16 * 16 + 16 * 16 + 16 * 8 + 4 +
+         8 * (size_t)slot_floats<N1, N2>();
 }
 
 // acc[t][r] of lane (c16, g4): row 4 g4 + r, column w CW + c16 T + t
@@ -230,7 +407,7 @@ template <int DP, int N0, int N1, int N2>
 __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::Args a) {
   using namespace step16;
   constexpr int T0 = N0 / 128, T1 = N1 / 128, T2 = N2 / 128, HL = N2;
-  static_assert(N0 % 128 == 0 && N1 % 128 == 0 && N2 % 128 == 0 && N0 <= 512 && N1 <= 512 && N2 <= 512, "eight waves x 16 T columns");
+  static_assert(N0 % 128 == 0 && N1 % 128 == 0 && N2 % 128 == 0 && N0 <= 512 && N1 <= 256 && N2 <= 256, "eight waves x 16 T columns; LDS-staged layers T <= 2");
   static_assert(DP % 16 == 0 && DP <= 256, "observation tile");
   constexpr int ldx = DP + kPad, ld0 = N0 + kPad, ld1 = N1 + kPad, ld2 = N2 + kPad;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -249,14 +426,27 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
   const int rows = (int)((a.M - r0) < kR ? (a.M - r0) : kR);
   const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* wslot = s_adv + 4 + wave * slot_floats<N1, N2>();   // this wave's weight slot (FwdL)
   const int A = g.A;
   const int RB = gridDim.x;
   const int NS = 2 * A + 1 + kHeadDiag;
   const float* P = a.params;
 
+  S16_TL(0);
   // ---- requests in front of everything: layer-0 weights, the observation tile, biases, the row-math operands
-  Fwd<T0, DP> L0;
-  L0.prefetch(P + a.off_w[net][0], wave, lane);
+  Fwd16<T0, DP> L0;
+  FwdL<T1, N0> L1;
+  FwdL<T2, N1> L2;
+  Bwd<T1, N2, N1> B2;                                  // dZ1 = (dZ2 . W2) * elu'(H1)
+  Bwd<T0, N1, N0> B1;                                  // dZ0 = (dZ1 . W1) * elu'(H0)
+  NoNext nonext;
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (int)(a.n_flat * 4), 0x00020000);
+  L0.init(prs, a.off_w[net][0], wave, lane);
+  L0.prefetch();
+  L1.init(prs, a.off_w[net][1], wave, lane, wslot);
+  L2.init(prs, a.off_w[net][2], wave, lane, wslot);
+  B2.init(prs, a.off_w[net][2], wave, lane);
+  B1.init(prs, a.off_w[net][1], wave, lane);
   {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(a.M * DP * 4), 0x00020000);
     constexpr int q4 = DP / 4, XQ = (kR * q4 + kThreads - 1) / kThreads;
@@ -272,31 +462,33 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
       if (f < kR * q4) *reinterpret_cast<u32x4*>(tX + r * ldx + 4 * q) = xr[j];
     }
   }
-  if (net == 1 && tid < 64) {           // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
-    if (g.hp.norm_adv && g.adv_stats == nullptr) {
-      double a1 = 0.0, a2 = 0.0;
-      for (int b = lane; b < g.n_adv_part; b += 64) {
-        a1 += g.adv_part[2 * b];
-        a2 += g.adv_part[2 * b + 1];
-      }
-      a1 = wave_sum_d(a1);
-      a2 = wave_sum_d(a2);
-      if (lane == 0) {
-        const double n = (double)g.M;
-        const double mean = a1 / n;
-        double var = (a2 - n * mean * mean) / (n - 1.0);   // NaN for n == 1, like torch.std()
-        if (var < 0.0) var = 0.0;
-        s_adv[0] = (float)mean;
-        s_adv[1] = (float)sqrt(var) + 1e-8f;
-      }
-    } else if (lane == 0) {
-      s_adv[0] = g.adv_stats ? g.adv_stats[0] : 0.0f;
-      s_adv[1] = g.adv_stats ? g.adv_stats[1] : 1.0f;
-    }
+  // advantage statistics over the minibatch (ppo.py:314-318: mean, unbiased std): wave 4 - idle while waves 0-3 compute
+  // the head outputs - requests its partial sums now and reduces them there
+  const bool adv_wave = net == 1 && wave == 4;
+  double adv_a1 = 0.0, adv_a2 = 0.0;
+  if (adv_wave && g.hp.norm_adv && g.adv_stats == nullptr && lane < g.n_adv_part) {
+    adv_a1 = g.adv_part[2 * lane];
+    adv_a2 = g.adv_part[2 * lane + 1];
   }
   const typename VecOf<T0>::type bias0 = *reinterpret_cast<const typename VecOf<T0>::type*>(P + a.off_b[net][0] + wave * 16 * T0 + c16 * T0);
   const typename VecOf<T1>::type bias1 = *reinterpret_cast<const typename VecOf<T1>::type*>(P + a.off_b[net][1] + wave * 16 * T1 + c16 * T1);
   const typename VecOf<T2>::type bias2 = *reinterpret_cast<const typename VecOf<T2>::type*>(P + a.off_b[net][2] + wave * 16 * T2 + c16 * T2);
+  __syncthreads();
+  S16_TL(1);
+
+  // ---- forward
+  f4v acc0[T0], acc1[T1], acc2[T2];
+  L0.run(tX, ldx, acc0, lane, L1);
+  S16_TL(2);
+  fwd_epilogue<T0, N0>(acc0, bias0, t0, a.H[net][0], a.M, r0, wave, lane);
+  __syncthreads();
+  S16_TL(3);
+  L1.run(t0, ld0, acc1, lane, L2);
+  S16_TL(4);
+  fwd_epilogue<T1, N1>(acc1, bias1, t1, a.H[net][1], a.M, r0, wave, lane);
+  __syncthreads();
+  S16_TL(5);
+  // (requested here, one layer ahead of their use, instead of at kernel entry: 14 VGPRs less through layers 0 and 1)
   // row math (wave 0): four threads per row, thread part pp owns the action dims pp, pp + 4, pp + 8, pp + 12
   const int rr = (tid >> 2) & 15, pp = tid & 3;
   const bool rvalid = rr < rows;
@@ -315,21 +507,8 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
     }
   }
   const float rbc = g.b4c[0], rvv = g.vrms_var[0], rvm = g.vrms_mean[0];
-  __syncthreads();
-
-  // ---- forward
-  f4v acc0[T0], acc1[T1], acc2[T2];
-  L0.run(tX, ldx, acc0, lane);
-  Fwd<T1, N0> L1;
-  L1.prefetch(P + a.off_w[net][1], wave, lane);
-  fwd_epilogue<T0, N0>(acc0, bias0, t0, a.H[net][0], a.M, r0, wave, lane);
-  __syncthreads();
-  L1.run(t0, ld0, acc1, lane);
-  Fwd<T2, N1> L2;
-  L2.prefetch(P + a.off_w[net][2], wave, lane);
-  fwd_epilogue<T1, N1>(acc1, bias1, t1, a.H[net][1], a.M, r0, wave, lane);
-  __syncthreads();
-  L2.run(t1, ld1, acc2, lane);
+  L2.run(t1, ld1, acc2, lane, B2);
+  S16_TL(6);
   // what the head steps and the first data gradient read from memory: requested before the last epilogue
   const float* Wh = net == 1 ? g.W4a : g.W4c;          // [KH][HL] head weights of this network
   const int KH = net == 1 ? A : 1;
@@ -349,10 +528,9 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
     for (int t = 0; t < T2; ++t) vset<T2>(z, t, 0.0f);
     bwB[i] = k < KH ? *reinterpret_cast<const typename VecOf<T2>::type*>(Wh + k * HL + wave * 16 * T2 + c16 * T2) : z;
   }
-  Bwd<T1, N2, N1> B2;                                  // dZ1 = (dZ2 . W2) * elu'(H1)
-  B2.prefetch(P + a.off_w[net][2], wave, lane);
   fwd_epilogue<T2, N2>(acc2, bias2, t2, nullptr, a.M, r0, wave, lane);
   __syncthreads();
+  S16_TL(7);
 
   // ---- A: head outputs Y[16][16] = H2 . Wh^T, waves 0-3 a quarter of the contraction each (fwd_head_kernel's order)
   {
@@ -365,6 +543,28 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
         STEP16_MFMA(av.y, bwA[kb].y, c);
         STEP16_MFMA(av.z, bwA[kb].z, c);
         STEP16_MFMA(av.w, bwA[kb].w, c);
+      }
+    }
+    if (adv_wave) {
+      if (g.hp.norm_adv && g.adv_stats == nullptr) {
+        double a1 = adv_a1, a2 = adv_a2;
+        for (int b = lane + 64; b < g.n_adv_part; b += 64) {
+          a1 += g.adv_part[2 * b];
+          a2 += g.adv_part[2 * b + 1];
+        }
+        a1 = wave_sum_d(a1);
+        a2 = wave_sum_d(a2);
+        if (lane == 0) {
+          const double n = (double)g.M;
+          const double mean = a1 / n;
+          double var = (a2 - n * mean * mean) / (n - 1.0);   // NaN for n == 1, like torch.std()
+          if (var < 0.0) var = 0.0;
+          s_adv[0] = (float)mean;
+          s_adv[1] = (float)sqrt(var) + 1e-8f;
+        }
+      } else if (lane == 0) {
+        s_adv[0] = g.adv_stats ? g.adv_stats[0] : 0.0f;
+        s_adv[1] = g.adv_stats ? g.adv_stats[1] : 1.0f;
       }
     }
     // the four quarters in fixed order, two rounds: sMu = q0 + q1, sG = q2 + q3 (sG is free until the row math writes
@@ -382,6 +582,7 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
     }
   }
 
+  S16_TL(8);
   // ---- row math (wave 0; the arithmetic of fwd_head_kernel / head_loss_kernel, ppo.py:299-345)
   const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
   if (wave == 0) {
@@ -465,6 +666,7 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
     }
   }
   __syncthreads();
+  S16_TL(9);
 
   // ---- C: head weight gradient of the tile, dWh[k][c] = sum_r G[r][k] H2[r][c]; wave w owns columns [w CW, w CW + CW)
   const int prow = net == 1 ? tile_i : RB + tile_i;
@@ -505,16 +707,18 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
     bwd_epilogue<T2, N2, true>(cb, t2, a.dZ[net][2], a.M, r0, wave, lane);
   }
   __syncthreads();
+  S16_TL(10);
 
   // ---- data gradients of the hidden layers
   f4v ax1[T1];
-  B2.run(t2, ld2, ax1, lane);
-  Bwd<T0, N1, N0> B1;                                  // dZ0 = (dZ1 . W1) * elu'(H0)
-  B1.prefetch(P + a.off_w[net][1], wave, lane);
+  B2.run(t2, ld2, ax1, lane, B1);
+  S16_TL(11);
   bwd_epilogue<T1, N1, true>(ax1, t1, a.dZ[net][1], a.M, r0, wave, lane);
   __syncthreads();
+  S16_TL(12);
   f4v ax0[T0];
-  B1.run(t1, ld1, ax0, lane);
+  B1.run(t1, ld1, ax0, lane, nonext);
+  S16_TL(13);
   bwd_epilogue<T0, N0, false>(ax0, t0, a.dZ[net][0], a.M, r0, wave, lane);
 
   // ---- scalars of the tile: bias / logstd gradients, diagnostics (rows in fixed order)
@@ -533,5 +737,6 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
       ps[2 * A + 1 + tid - 32] = v;                        // diagnostics
     }
   }
+  S16_TL(14);
 }
 #undef STEP16_MFMA
