@@ -748,7 +748,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       // split for ~512 workgroups with at least 128 contraction rows each.  At 2048 samples the old rule cut a
       // 256x512 layer into 2048 workgroups of 64 rows - four slabs of work between a prologue and a 33 MB partial store.
       const int t64 = ((out + 63) / 64) * ((in + 63) / 64) * 2;
-      splits = 512 / (t64 > 0 ? t64 : 1);
+      static const int target_wg = env_int("CATPPO_DW_TARGET_WG", 512);      // A/B: workgroups a 64x64-tile weight gradient aims for
+      splits = target_wg / (t64 > 0 ? t64 : 1);
       const int max128 = (int)(M / 128);
       if (splits > max128) splits = max128;
       if (splits > split_cap(out, in)) splits = split_cap(out, in);

@@ -37,6 +37,10 @@ int layout_of(const catppo_mlp_shape* s, catppo_mlp_layout* L) {
     for (int l = 0; l <= nl; ++l) {
       const int out = l < nl ? s->hidden[l] : (net == 0 ? 1 : s->act_dim);
       L->out_dim[net][l] = out;
+      // every weight matrix starts on a 128-byte line (round 6): with 16-byte alignment the rows of the hidden layers -
+      // 1 or 2 KB each - all began 48 bytes into a line, so every coalesced 128-byte row segment of the row-resident kernels
+      // straddled two lines (twice the tag look-ups, the second line re-fetched by the next slab's request)
+      off = (off + 31) / 32 * 32;
       L->off_w[net][l] = off;
       off += r4((int64_t)out * L->in_dim[l]);
       L->off_b[net][l] = off;

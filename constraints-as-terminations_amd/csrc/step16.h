@@ -100,6 +100,10 @@ __device__ __forceinline__ void bstore(const typename VecOf<T>::type& v, __amdgp
 //   i = 0: k {0,4,1,5}[g4]   i = 1: {2,6,3,7}   i = 2: {8,12,9,13}   i = 3: {10,14,11,15}
 // (v_permlane32_swap a, b: a <- [a.lo | b.lo], b <- [a.hi | b.hi] over the two 32-lane halves)
 __device__ __forceinline__ void prep(const f4v v, float (&o)[4]) {
+#ifdef STEP16_EXP_NOSWAP        // timing experiment (tools/step16_timeline.py): wrong results, never in the product build
+  o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+  return;
+#endif
   const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.x), __float_as_uint(v.y), false, false);
   const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v.z), __float_as_uint(v.w), false, false);
   o[0] = __uint_as_float(s0[0]), o[2] = __uint_as_float(s0[1]);
@@ -108,13 +112,29 @@ __device__ __forceinline__ void prep(const f4v v, float (&o)[4]) {
 // first k row (inside a unit) lane group g4 supplies for operand i of an I-contiguous operand: same order as prep()
 __device__ __forceinline__ int krow_of(int i, int g4) { return 8 * (i >> 1) + 2 * (i & 1) + (g4 >> 1) + 4 * (g4 & 1); }
 
-#ifdef STEP16_TL   // tools/step16_timeline.py: thread 0 of every workgroup stamps the 100 MHz wall clock at the phase boundaries
-__device__ unsigned long long* g_s16tl;    // [2 networks][4096 tiles][16 stamps]
-#define S16_TL(i) do { if (threadIdx.x == 0 && g_s16tl) g_s16tl[(blockIdx.y * 4096 + blockIdx.x) * 16 + (i)] = wall_clock64(); } while (0)
+#ifdef STEP16_TL   // tools/step16_timeline.py: lane 0 of every wave stamps the 100 MHz wall clock at the phase boundaries
+__device__ unsigned long long* g_s16tl;    // [2 networks][1024 tiles][8 waves][16 stamps]
+#define S16_TL(i) do { if ((threadIdx.x & 63) == 0 && g_s16tl && blockIdx.x < 1024) g_s16tl[((blockIdx.y * 1024 + blockIdx.x) * 8 + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define S16_TL(i) do { } while (0)
 #endif
 
+// Two waves share a SIMD and run the same instruction stream from the same barrier.  Left alone they stay in phase: both
+// in their LDS block (eight waves' ds_write_b128 / ds_read_b128 serialise on the CU's LDS: ~600 cycles per 32-k stage, the
+// matrix pipe idle), then both in their MFMA block (2 x 512 cycles) - 1600 cycles per stage where the pipe needs 1024
+// (profiles/r6_step16_timeline_waves.txt, tools/swap_probe.hip).  Raising the priority inside the MFMA block does not
+// break the symmetry (both waves raise it at the same time: measured no change).  A PERMANENT difference does: waves
+// 0-3 (one per SIMD: a workgroup's waves are dealt to the SIMDs cyclically) run at priority 2, waves 4-7 at 0 - the
+// first wave of a SIMD runs its stages at its own pace and the second one's MFMA blocks fill the gaps its LDS / lane-swap
+// blocks leave.  STEP16_PRIO_MODE: 0 off, 1 raised inside MFMA blocks, 2 (default) the permanent split.
+#ifndef STEP16_PRIO_MODE
+#define STEP16_PRIO_MODE 2
+#endif
+#if STEP16_PRIO_MODE == 1
+#define STEP16_PRIO(p_) __builtin_amdgcn_s_setprio(p_)
+#else
+#define STEP16_PRIO(p_) do { } while (0)
+#endif
 #define STEP16_MFMA(a_, b_, c_) c_ = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, b_, c_, 0, 0, 0)
 
 // Weight streams.  Every layer object owns a register ring of DE pipeline elements (Fwd16 / Bwd: one 16-k unit; Fwd32: one
@@ -184,10 +204,14 @@ struct Fwd16 {
       const int c = j & 1, n = c ^ 1;
       f4v af;
       if (j + 1 < NE) af = *reinterpret_cast<const f4v*>(ap + 16 * (j + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      STEP16_PRIO(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int t = 0; t < T; ++t) STEP16_MFMA(a[c][i], b[c][t][i], acc[t]);
+      STEP16_PRIO(0);
+      __builtin_amdgcn_sched_barrier(0);
       if (j + 1 < NE) {
         prep(af, a[n]);
 #pragma unroll
@@ -247,8 +271,13 @@ struct FwdL {
   };
   // stage j: registers -> slot -> operand fragments (+ the activation fragments of the stage)
   __device__ __forceinline__ void stage_in(Raw& r, const float* __restrict__ ap, int j) {
+#ifdef STEP16_EXP_NOLDSW       // timing experiment: the slot is never written (the requests still have to arrive)
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) asm volatile("" ::"v"(ring[j % DE][i]));
+#else
 #pragma unroll
     for (int i = 0; i < NLD; ++i) *reinterpret_cast<f4v*>(wr + 8 * i * S) = ring[j % DE][i];
+#endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       r.a[u] = *reinterpret_cast<const f4v*>(ap + 32 * j + 16 * u);
@@ -279,14 +308,22 @@ struct FwdL {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {                      // one scheduling region per stage, see Fwd16::run
       const int c = j & 1, n = c ^ 1;
+      // three sub-regions, in issue order: (1) stage j + 1 into the slot and its fragments requested back, (2) the
+      // MFMAs of stage j - 8 T x 32 cycles of matrix pipe, behind which the LDS round trip of (1) completes - (3) the lane
+      // swaps that turn the fragments into operands.  Left to itself the compiler puts the swaps between the MFMAs,
+      // right behind the ds_reads they wait for: one exposed LDS latency in the middle of every stage.
       Raw r;
       if (j + 1 < NE) stage_in(r, ap, j + 1);           // (every fragment of stage j was read in the previous region)
+      __builtin_amdgcn_sched_barrier(0);
+      STEP16_PRIO(1);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int t = 0; t < T; ++t) STEP16_MFMA(ops[c].a[u][i], ops[c].b[u][t][i], acc[t]);
+      STEP16_PRIO(0);
+      __builtin_amdgcn_sched_barrier(0);
       if (j + 1 < NE) make_ops(ops[n], r);
       stream_next(*this, nx, j);
     }
@@ -330,10 +367,14 @@ struct Bwd {
       const int c = j & 1, n = c ^ 1;
       f4v af;
       if (j + 1 < NE) af = *reinterpret_cast<const f4v*>(ap + 16 * (j + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      STEP16_PRIO(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int t = 0; t < T; ++t) STEP16_MFMA(a[c][i], vget<T>(ring[j % DE][i], t), acc[t]);
+      STEP16_PRIO(0);
+      __builtin_amdgcn_sched_barrier(0);
       if (j + 1 < NE) prep(af, a[n]);
       stream_next(*this, nx, j);
     }
@@ -427,6 +468,10 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
   const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15, g4 = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* wslot = s_adv + 4 + wave * slot_floats<N1, N2>();   // this wave's weight slot (FwdL)
+#if STEP16_PRIO_MODE == 2
+  if (wave < 4) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
   const int A = g.A;
   const int RB = gridDim.x;
   const int NS = 2 * A + 1 + kHeadDiag;

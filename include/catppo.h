@@ -259,8 +259,9 @@ int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, int D, int6
 /* ---- actor-critic MLP ---------------------------------------------------------------------
  * Two independent MLPs (critic then actor, the reference's registration order) with L
  * hidden layers, ELU(alpha=1).  All parameters, gradients and Adam moments live in flat
- * fp32 buffers laid out by catppo_mlp_layout (segments 16-byte aligned, first-layer rows
- * padded from D to Dp = round_up(D,16) with zeros).
+ * fp32 buffers laid out by catppo_mlp_layout (segments 16-byte aligned, weight matrices
+ * 128-byte aligned, first-layer rows padded from D to Dp = round_up(D,16) with zeros; the
+ * padding between segments is never read as a parameter and never written by a gradient).
  * replaces: cleanrl/ppo.py:71-123 (Agent), :300-354 (minibatch update). */
 #define CATPPO_MAX_HIDDEN 4
 

@@ -41,24 +41,32 @@ def main():
     run = lambda: nat.ppo_minibatch_grad(shape, hp, flat, obs, act, logp, adv, ret, val, inds, zero, one, None, grad, diag)
     lib = nat.lib
     lib.catppo_debug_step16_tl.restype, lib.catppo_debug_step16_tl.argtypes = C.c_int, [C.c_void_p]
-    buf = torch.zeros(2 * 4096 * 16, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(2 * 1024 * 8 * 16, dtype=torch.int64, device="cuda")
     for _ in range(5):
         run()
     torch.cuda.synchronize()
     assert lib.catppo_debug_step16_tl(buf.data_ptr()) == 0
     run()
     torch.cuda.synchronize()
-    raw = buf.cpu().numpy().reshape(2, 4096, 16).astype(np.float64) * 0.01     # 100 MHz -> us
-    n_t = -(-M // 16)
+    raw = buf.cpu().numpy().reshape(2, 1024, 8, 16).astype(np.float64) * 0.01     # 100 MHz -> us
+    n_t = min(-(-M // 16), 1024)
+    t0 = raw[:, :n_t, :, 0][raw[:, :n_t, :, 0] > 0].min()
     for ni, nm in ((0, "critic"), (1, "actor")):
-        t = raw[ni, :n_t, :15]
-        t0 = raw[:, :n_t, 0][raw[:, :n_t, 0] > 0].min()
-        print("%s workgroups (%d): entry %.2f .. %.2f us after the first workgroup of the launch, exit median %.2f max %.2f"
-              % (nm, n_t, t[:, 0].min() - t0, t[:, 0].max() - t0, np.median(t[:, 14]) - t0, t[:, 14].max() - t0))
-        d = np.diff(t, axis=1)
+        t = raw[ni, :n_t, :, :15]                                  # [tile][wave][stamp]
+        print("%s workgroups (%d): entry %.2f .. %.2f us after the first wave of the launch, exit median %.2f max %.2f"
+              % (nm, n_t, t[:, :, 0].min() - t0, t[:, :, 0].max() - t0, np.median(t[:, :, 14]) - t0, t[:, :, 14].max() - t0))
+        # per phase: duration seen by wave 0, and the spread of the waves' ARRIVAL at the end of the phase
+        d = np.diff(t, axis=2)
         for i in range(14):
-            print("   %-40s median %6.2f us   (p10 %6.2f  p90 %6.2f)" % (NAMES[i + 1], np.median(d[:, i]), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
-        print("   %-40s median %6.2f us" % ("workgroup total", np.median(t[:, 14] - t[:, 0])))
+            arr = t[:, :, i + 1]
+            skew = arr.max(axis=1) - arr.min(axis=1)
+            print("   %-40s wave0 %6.2f us | fastest wave %6.2f  slowest wave %6.2f | arrival skew across the 8 waves %5.2f us"
+                  % (NAMES[i + 1], np.median(d[:, 0, i]), np.median(d[:, :, i].min(axis=1)), np.median(d[:, :, i].max(axis=1)), np.median(skew)))
+        print("   %-40s median %6.2f us" % ("workgroup total", np.median(t[:, :, 14].max(axis=1) - t[:, :, 0].min(axis=1))))
+        w = t[n_t // 2]                                            # one workgroup, every wave: cumulative times
+        print("   one workgroup (tile %d), us since its first wave started; rows = waves 0..7" % (n_t // 2))
+        for wv in range(8):
+            print("      " + " ".join("%6.2f" % (x - w[:, 0].min()) for x in w[wv]))
 
 
 if __name__ == "__main__":
