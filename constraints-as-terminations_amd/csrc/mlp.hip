@@ -262,6 +262,48 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
   CATPPO_CHECK_ARG(ctx, value_dtype == CATPPO_F32 || value_dtype == CATPPO_F16);
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
+    // round 6: 16-row tiles (step16.h) for batches below the 32-row kernels' window - 2048 envs of an env-sharded rank, cfg1.
+    // CATPPO_STEP16_FWD=0 keeps the layer-wise launches (A/B); CATPPO_STEP16_FWD_MAX_ROWS moves the bound.
+    static const int s16f_on = env_int("CATPPO_STEP16_FWD", 1);
+    static const int s16f_max = env_int("CATPPO_STEP16_FWD_MAX_ROWS", 2048);
+    if (s16f_on && N <= s16f_max && shape->mfma_bf16 == 0 && shape->n_hidden == 3 && N * 512 * 4 < (int64_t(1) << 31)) {
+      FusedFwdArgs fa{};
+      fa.x = x, fa.params = params, fa.M = N, fa.Dp = L.obs_pad, fa.n_hidden = 3, fa.n_flat = L.n_flat;
+      for (int net = 0; net < 2; ++net)
+        for (int l = 0; l <= 3; ++l) fa.off_w[net][l] = L.off_w[net][l], fa.off_b[net][l] = L.off_b[net][l];
+      fa.net0 = 0;
+      fa.logstd = params + L.off_logstd, fa.eps = eps, fa.given = given_action, fa.A = shape->act_dim;
+      fa.action = action, fa.logprob = logprob, fa.value_out = value, fa.value_f16 = (int)(value_dtype == CATPPO_F16);
+      fa.rng_state = rng_state, fa.rng_step = rng_step, fa.eps_out = eps_out, fa.do_head = 1;
+      bool done16 = false;
+      const int tiles16 = (int)cdiv64(N, step16::kR);
+      auto launch16 = [&](auto dp, auto n0, auto n1, auto n2) {
+        constexpr int DP = decltype(dp)::value, N0 = decltype(n0)::value, N1 = decltype(n1)::value, N2 = decltype(n2)::value;
+        constexpr size_t lds = sizeof(float) * step16::lds_floats<DP, N0, N1, N2>();
+        auto kern = step16_fwd_kernel<DP, N0, N1, N2>;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)tiles16, critic_only ? 1 : 2), dim3(step16::kThreads), lds, s, fa);
+        done16 = true;
+      };
+      using std::integral_constant;
+      const int h0 = shape->hidden[0], h1 = shape->hidden[1], h2 = shape->hidden[2];
+#define CATPPO_S16(DP_, A_, B_, C_)                                                                          \
+      if (!done16 && L.obs_pad == DP_ && h0 == A_ && h1 == B_ && h2 == C_)                                    \
+        launch16(integral_constant<int, DP_>{}, integral_constant<int, A_>{}, integral_constant<int, B_>{},  \
+                 integral_constant<int, C_>{});
+      CATPPO_S16(48, 512, 256, 128)
+      CATPPO_S16(48, 256, 256, 256)
+#undef CATPPO_S16
+      if (done16) {
+        catppo_plan_note(ctx, "rollout forward, %lld rows: step16_fwd_kernel<%d, %d, %d, %d> + heads, %d tiles of 16 rows x %d networks, ONE "
+                         "launch [<= %d rows, fp32, a compiled shape]", (long long)N, L.obs_pad, h0, h1, h2, tiles16, critic_only ? 1 : 2, s16f_max);
+        CATPPO_CHECK_LAUNCH(ctx);
+        return CATPPO_OK;
+      }
+    }
+  }
+  {
     // row-resident forward with full-line weight loads (round 4) for networks whose hidden layers are all 256 wide, same
     // window as fused_fwd_kernel (which keeps the other shapes): 32.1 -> 30 us per env step at cfg2, rollout 1.75 -> 1.70 ms
     // (interleaved A/B, profiles/r4_ab_rows_fwd.txt); CATPPO_ROWS_FWD_ROLLOUT=0 falls back to fused_fwd_kernel
@@ -521,7 +563,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   {
     static const int s16_on = env_int("CATPPO_STEP16", 1);
     static const int s16_max = env_int("CATPPO_STEP16_MAX_ROWS", 4096);
-    const bool plain = !ctx->use_side && !(ctx->grad_overlap == 1 && ctx->comm != nullptr);
+    const bool plain = !ctx->use_side;      // (the side-stream experiment forks per layer: layer-wise launches only)
     if (s16_on && plain && M <= s16_max && shape->mfma_bf16 == 0 && nl == 3 && A <= 15 && M * 512 * 4 < (int64_t(1) << 31)) {
       step16::Args sa{};
       sa.x = w.xmb, sa.params = params, sa.M = M, sa.n_flat = L.n_flat;
@@ -710,10 +752,12 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const bool fork = ctx->use_side;
   // catppo_set_grad_overlap + a communicator: fold and all-reduce the gradient in per-layer buckets on the side stream
   // while the backward launches of the layers below run on `s` (see the end of the layer loop)
-  const bool overlap = !fork && ctx->grad_overlap == 1 && ctx->comm != nullptr;
+  // (the 16-row step has no per-layer launches to hide buckets behind: with either overlap mode it folds once and reduces
+  // the whole gradient in one grouped operation, the `tail` form's fallback below)
+  const bool overlap = !fork && ctx->grad_overlap == 1 && ctx->comm != nullptr && !step16_done;
   // round 5, "tail" form: no extra launch; the ranges that are final after dw_fold_kernel travel on the side stream under
   // the final fold launch, the first layer's own ranges behind it on `s`
-  const bool tail = !fork && ctx->grad_overlap == 2 && ctx->comm != nullptr;
+  const bool tail = !fork && ctx->comm != nullptr && (ctx->grad_overlap == 2 || (ctx->grad_overlap == 1 && step16_done));
   bool tail_forked = false;
   if (ne != nullptr && (fork || overlap || tail))
     return catppo_fail(ctx, CATPPO_E_ARG, "%s: the one-call optimiser step cannot run with the side-stream weight "

@@ -141,6 +141,7 @@ struct FusedFwdArgs {
   float* eps_out;
   int do_head;
   int nets_per_wg;                 // rows_fwd_kernel: 2 = one workgroup walks both networks (grid.y == 1), 1 = grid.y == nets
+  int64_t n_flat;                  // step16_fwd_kernel: floats in the flat parameter buffer (buffer descriptor range)
   int store_policy;                // rows_fwd_kernel activation stores: 0 all write-through (sc1), 1 write-through only for the
                                    // last layer of the last network a workgroup walks (the rest may sit in L2: they have the
                                    // rest of the launch to drain), 2 none
@@ -151,7 +152,7 @@ struct FusedFwdArgs {
 // 32 rows, so the wave-per-row form costs 8 serial rows of ~2500 dependent cycles each (8 us of a 45 us kernel).  Here
 // the work is spread over items: actor = (row, action slot) with the 16 slots of a row in 16 adjacent lanes (two items
 // per thread), critic = (row, eighth of the contraction) with 8 lanes per row.
-template <int HL>
+template <int HL, int ROWS = 32>      // ROWS: rows of the tile (32: fused_fwd / rows_fwd kernels; 16: step16_fwd_kernel - items of rows >= ROWS are masked)
 __device__ __forceinline__ void fused_head(const FusedFwdArgs& a, const float* __restrict__ hs, int ld, int net,
                                            int64_t r0, float* __restrict__ wlds) {
   constexpr int WL = HL + 4;                       // padded weight rows: 16 slots read the same column without conflicts
@@ -184,7 +185,7 @@ __device__ __forceinline__ void fused_head(const FusedFwdArgs& a, const float* _
     d += __shfl_xor(d, 4, 64);
     d += __shfl_xor(d, 8, 64);
     const float v = d + b4[0];
-    if (part == 0 && i < a.M) {
+    if (part == 0 && i < a.M && r < ROWS) {
       if (a.value_f16) reinterpret_cast<_Float16*>(a.value_out)[i] = (_Float16)v;
       else reinterpret_cast<float*>(a.value_out)[i] = v;
     }
@@ -203,7 +204,7 @@ __device__ __forceinline__ void fused_head(const FusedFwdArgs& a, const float* _
   {
     const int r = tid >> 4;                        // one (row, slot) item per thread
     const int64_t i = r0 + r;
-    const bool mine = kin && i < a.M;
+    const bool mine = kin && i < a.M && r < ROWS;
     const float* hp = hs + r * ld;
     const float* wp = wlds + k * WL;
     float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
@@ -238,7 +239,7 @@ __device__ __forceinline__ void fused_head(const FusedFwdArgs& a, const float* _
     lp += __shfl_xor(lp, 4, 64);
     lp += __shfl_xor(lp, 8, 64);
     if (mine) a.action[i * A + k] = act;
-    if (k == 0 && i < a.M) a.logprob[i] = lp;
+    if (k == 0 && i < a.M && r < ROWS) a.logprob[i] = lp;
   }
 }
 

@@ -784,4 +784,70 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
   }
   S16_TL(14);
 }
+
+// Rollout forward on the same 16-row tiles (policy step + value, cleanrl/ppo.py:104-119,186-189; bootstrap value :251):
+// the three layers of step16_kernel and the heads of the row-resident rollout kernels (fused_head: Philox action noise,
+// log-prob, value).  For batches that leave the 32-row kernels with fewer workgroups than CUs - an env-sharded rank's 2048
+// envs ran three layer-wise GEMM launches + head_act_kernel (36 us per env step).  grid = (16-row tiles, networks).
+template <int DP, int N0, int N1, int N2>
+__global__ __launch_bounds__(step16::kThreads) void step16_fwd_kernel(const FusedFwdArgs a) {
+  using namespace step16;
+  constexpr int T0 = N0 / 128, T1 = N1 / 128, T2 = N2 / 128;
+  constexpr int ldx = DP + kPad, ld0 = N0 + kPad, ld1 = N1 + kPad, ld2 = N2 + kPad;
+  static_assert(16 * (N2 + 4) <= kR * ld0, "the head weights are staged over the first activation tile");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tX = smem;
+  float* t0 = tX + kR * ldx;
+  float* t1 = t0 + kR * ld0;
+  float* t2 = t1 + kR * ld1;
+  const int net = a.net0 + blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.x * kR;
+  const int tid = threadIdx.x, lane = tid & 63, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* wslot = t2 + kR * ld2 + wave * slot_floats<N1, N2>();
+  const float* P = a.params;
+  Fwd16<T0, DP> L0;
+  FwdL<T1, N0> L1;
+  FwdL<T2, N1> L2;
+  NoNext nonext;
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P), 0, (int)(a.n_flat * 4), 0x00020000);
+  L0.init(prs, a.off_w[net][0], wave, lane);
+  L0.prefetch();
+  L1.init(prs, a.off_w[net][1], wave, lane, wslot);
+  L2.init(prs, a.off_w[net][2], wave, lane, wslot);
+  {
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)(a.M * DP * 4), 0x00020000);
+    constexpr int q4 = DP / 4, XQ = (kR * q4 + kThreads - 1) / kThreads;
+    u32x4 xr[XQ];
+#pragma unroll
+    for (int j = 0; j < XQ; ++j) {
+      const int f = tid + j * kThreads, r = f / q4, q = f - r * q4;
+      xr[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, f < kR * q4 ? (uint32_t)(((r0 + r) * DP + 4 * q) * 4) : 0xffffffffu, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < XQ; ++j) {
+      const int f = tid + j * kThreads, r = f / q4, q = f - r * q4;
+      if (f < kR * q4) *reinterpret_cast<u32x4*>(tX + r * ldx + 4 * q) = xr[j];
+    }
+  }
+  const typename VecOf<T0>::type bias0 = *reinterpret_cast<const typename VecOf<T0>::type*>(P + a.off_b[net][0] + wave * 16 * T0 + c16 * T0);
+  const typename VecOf<T1>::type bias1 = *reinterpret_cast<const typename VecOf<T1>::type*>(P + a.off_b[net][1] + wave * 16 * T1 + c16 * T1);
+  const typename VecOf<T2>::type bias2 = *reinterpret_cast<const typename VecOf<T2>::type*>(P + a.off_b[net][2] + wave * 16 * T2 + c16 * T2);
+#if STEP16_PRIO_MODE == 2
+  if (wave < 4) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+  __syncthreads();
+  f4v acc0[T0], acc1[T1], acc2[T2];
+  L0.run(tX, ldx, acc0, lane, L1);
+  fwd_epilogue<T0, N0>(acc0, bias0, t0, nullptr, a.M, r0, wave, lane);
+  __syncthreads();
+  L1.run(t0, ld0, acc1, lane, L2);
+  fwd_epilogue<T1, N1>(acc1, bias1, t1, nullptr, a.M, r0, wave, lane);
+  __syncthreads();
+  L2.run(t1, ld1, acc2, lane, nonext);
+  fwd_epilogue<T2, N2>(acc2, bias2, t2, nullptr, a.M, r0, wave, lane);
+  __syncthreads();
+  if (a.do_head) fused_head<N2, kR>(a, t2, ld2, net, r0, t0);      // (the first activation tile is free: head weights go there)
+}
 #undef STEP16_MFMA

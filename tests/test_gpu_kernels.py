@@ -776,8 +776,8 @@ def test_fused_forward_launch_equals_the_layerwise_path(tmp_path):
     cases = {"cfg2": (48, 12, (256, 256, 256), 4096), "ref_ragged": (45, 12, (512, 256, 128), 2049),
              "tiny": (45, 12, (512, 256, 128), 33), "wide_head": (33, 7, (128, 512), 300), "one_row": (48, 12, (256, 128), 1)}
     outs = []
-    for env_over in (dict(CATPPO_FUSED_FWD="1", CATPPO_FUSED_FWD_MIN_ROWS="1", CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_ROWS_WIDE="0"),
-                     dict(CATPPO_FUSED_FWD="0", CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_ROWS_WIDE="0")):
+    for env_over in (dict(CATPPO_FUSED_FWD="1", CATPPO_FUSED_FWD_MIN_ROWS="1", CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_ROWS_WIDE="0", CATPPO_STEP16_FWD="0"),
+                     dict(CATPPO_FUSED_FWD="0", CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_ROWS_WIDE="0", CATPPO_STEP16_FWD="0")):
         out = str(tmp_path / f"ff{len(outs)}.npz")
         code = _FUSED_FWD_AB.format(root=root, cases=cases, out=out)
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True,

@@ -177,7 +177,7 @@ def test_row_resident_forward_equals_the_layerwise_launches(tmp_path, D, A, hidd
     for flag in ("1", "0"):
         out = str(tmp_path / f"rows{flag}.npz")
         code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=0, out=out)
-        env = dict(os.environ, CATPPO_ROWS_FWD=flag, CATPPO_ROWS_FWD_MIN_ROWS="1")
+        env = dict(os.environ, CATPPO_ROWS_FWD=flag, CATPPO_ROWS_FWD_MIN_ROWS="1", CATPPO_STEP16="0")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
@@ -193,7 +193,7 @@ def test_row_resident_rollout_forward_equals_the_layerwise_path(tmp_path):
     cases = {"cfg2": (48, 12, (256, 256, 256), 4096), "ragged": (45, 12, (256, 256, 256), 2049),
              "tiny": (48, 7, (256, 256), 33), "wide_obs": (235, 12, (256, 256, 256), 300), "one_row": (48, 12, (256,), 1)}
     outs = []
-    for env_over in (dict(CATPPO_ROWS_FWD_ROLLOUT="1", CATPPO_FUSED_FWD_MIN_ROWS="1"),
+    for env_over in (dict(CATPPO_ROWS_FWD_ROLLOUT="1", CATPPO_FUSED_FWD_MIN_ROWS="1", CATPPO_STEP16_FWD="0"),
                      dict(CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_FUSED_FWD="0")):
         out = str(tmp_path / f"rr{len(outs)}.npz")
         code = TK._FUSED_FWD_AB.format(root=ROOT, cases=cases, out=out)
@@ -242,7 +242,7 @@ def test_row_resident_forward_every_slab_count_of_the_first_layer(tmp_path, D):
     for flag in ("1", "0"):
         out = str(tmp_path / f"rows{flag}.npz")
         code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=12, hidden=(256, 256, 256), Bsz=4101, M=4101, prec=0, out=out)
-        env = dict(os.environ, CATPPO_ROWS_FWD=flag, CATPPO_ROWS_FWD_MIN_ROWS="1")
+        env = dict(os.environ, CATPPO_ROWS_FWD=flag, CATPPO_ROWS_FWD_MIN_ROWS="1", CATPPO_STEP16="0")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))

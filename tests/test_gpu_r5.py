@@ -258,7 +258,7 @@ def test_shape_generic_row_resident_forward_equals_the_layerwise_launches(tmp_pa
     for flag in ("1", "0"):
         out = str(tmp_path / f"wide{flag}.npz")
         code = TK._FUSED_VS_SPLIT.format(root=ROOT, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=0, out=out)
-        env = dict(os.environ, CATPPO_ROWS_WIDE=flag, CATPPO_ROWS_FWD_MIN_ROWS="1")
+        env = dict(os.environ, CATPPO_ROWS_WIDE=flag, CATPPO_ROWS_FWD_MIN_ROWS="1", CATPPO_STEP16="0")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
@@ -276,7 +276,7 @@ def test_shape_generic_row_resident_rollout_forward_equals_the_layerwise_path(tm
              "ref_tiny": (45, 12, (512, 256, 128), 33), "n128": (48, 7, (128, 128), 300), "one_row": (48, 12, (512, 256), 1),
              "mixed": (30, 5, (256, 128, 256), 1000), "obs64": (64, 12, (512, 128), 257)}
     outs = []
-    for env_over in (dict(CATPPO_ROWS_WIDE="1", CATPPO_FUSED_FWD_MIN_ROWS="1"),
+    for env_over in (dict(CATPPO_ROWS_WIDE="1", CATPPO_FUSED_FWD_MIN_ROWS="1", CATPPO_STEP16_FWD="0"),
                      dict(CATPPO_ROWS_WIDE="0", CATPPO_FUSED_FWD="0", CATPPO_ROWS_FWD_ROLLOUT="0")):
         out = str(tmp_path / f"wr{len(outs)}.npz")
         code = TK._FUSED_FWD_AB.format(root=ROOT, cases=cases, out=out)
@@ -306,8 +306,11 @@ def test_plan_log_names_the_kernels_a_shape_gets():
     ref = E.explain(45, 12, (512, 256, 128), 4096, 16384)
     assert "rows_fwd_wide_kernel<32> + heads" in ref and "rows_fwd_wide_kernel<64>" in ref and "in 2 chunk(s)" in ref
     assert "fwd_head_kernel<128, prec 0>" in ref
-    shard = E.explain(45, 12, (512, 256, 128), 2048, 2048)
-    assert "layer-wise" in shard and "head_loss_kernel" in shard and "64x64 weight-gradient tiles" in shard
+    shard = E.explain(45, 12, (512, 256, 128), 2048, 2048)       # round 6: an 8-way shard's batch takes the 16-row kernels
+    assert "step16_fwd_kernel<48, 512, 256, 128> + heads" in shard and "step16_kernel<48, 512, 256, 128>" in shard
+    assert "dw_multi_kernel" in shard and "gemm_pair_kernel" not in shard and "head_loss_kernel" not in shard
+    odd = E.explain(45, 12, (512, 128, 128), 2048, 2048)         # a shape without a compiled 16-row kernel: the layer-wise path
+    assert "layer-wise" in odd and "head_loss_kernel" in odd and "64x64 weight-gradient tiles" in odd
     from cat_envs import native
     nat = native.get(torch.device("cuda", 0))
     assert nat.plan_log(-1) == nat.plan_log(-1) and "clip + Adam" in nat.plan_log(-1)      # reading does not clear

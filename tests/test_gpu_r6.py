@@ -67,3 +67,28 @@ def test_small_minibatch_step_against_the_default_small_path(tmp_path):
     scale = float(np.abs(old["grad"]).max())
     np.testing.assert_allclose(new["grad"], old["grad"], rtol=0, atol=3e-6 * scale)
     np.testing.assert_allclose(new["diag"], old["diag"], rtol=3e-6, atol=1e-7)
+
+
+def test_16_row_rollout_forward_equals_the_layerwise_path(tmp_path):
+    """step16_fwd_kernel (16-row tiles, three layers + rollout heads in one launch; cleanrl/ppo.py:104-119) against the
+    layer-wise rollout forward at the batch sizes below the 32-row kernels' window: hidden layers bit-identical by
+    construction, heads sum in another order (2e-6), Philox noise exact; ragged and one-row batches, critic-only call."""
+    import test_gpu_kernels as TK
+    cases = {"shard": (45, 12, (512, 256, 128), 2048), "ragged": (45, 12, (512, 256, 128), 1001), "tiny": (45, 12, (512, 256, 128), 33),
+             "cfg1": (48, 12, (512, 256, 128), 64), "cfg2net": (48, 12, (256, 256, 256), 2048), "one_row": (48, 7, (256, 256, 256), 1)}
+    outs = []
+    for env_over in (dict(CATPPO_STEP16_FWD="1"), dict(CATPPO_STEP16_FWD="0", CATPPO_FUSED_FWD="0", CATPPO_ROWS_FWD_ROLLOUT="0", CATPPO_ROWS_WIDE="0")):
+        out = str(tmp_path / f"s16f{len(outs)}.npz")
+        code = TK._FUSED_FWD_AB.format(root=ROOT, cases=cases, out=out)
+        code = code.replace("np.savez(", "nat.plan_log(1); nat.value(shape, params, T.dev(x), B, v2); open({!r}, 'w').write(nat.plan_log(-1)); np.savez(".format(out + ".plan"))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append((np.load(out), open(out + ".plan").read()))
+    (f, pf), (l, pl) = outs
+    assert "step16_fwd_kernel" in pf and "step16_fwd_kernel" not in pl and "layer-wise" in pl
+    for k in f.files:
+        if k.endswith("_e3"):
+            np.testing.assert_array_equal(f[k], l[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(f[k], l[k], rtol=0, atol=2e-6 * max(1.0, float(np.abs(l[k]).max())), err_msg=k)
+    assert np.abs(f["shard_act"]).max() > 0 and np.isfinite(f["ragged_lp"]).all()
