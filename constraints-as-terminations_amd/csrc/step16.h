@@ -96,6 +96,55 @@ __device__ __forceinline__ void bstore(const typename VecOf<T>::type& v, __amdgp
   else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rs, off, 0, 16);
 }
 
+// OPERAND-ORDER TILES.  Operand i of lane group g4 in a 16-k unit must carry k = kperm(i, g4) = 8 (i >> 1) + 2 (i & 1) +
+// (g4 >> 1) + 4 (g4 & 1) (gemm_body's contraction order).  A tile / slot row that stores the 16 k of a unit in the order
+//     position:  0 1 2 3 | 4 5 6  7  | 8 9 10 11 | 12 13 14 15
+//     k       :  0 2 8 10| 4 6 12 14 | 1 3 9  11 | 5  7  13 15        pos(k) = b0 << 3 | b2 << 2 | b3 << 1 | b1
+// hands lane group g4 its four operands with ONE ds_read_b128 of chunk g4 - no lane swaps.  (With k stored in natural order
+// every fragment cost two v_permlane32_swap, ~13 cycles of the SIMD each: 12 per 32-k stage and wave at T = 2, 2.3 us of
+// the 512-k layer - profiles/r6_step16_timeline_noswap.txt.)  Writers place values with pos(): four consecutive k
+// (4 m .. 4 m + 3) are two adjacent pairs - (k, k + 2) at pos(k), (k + 1, k + 3) at pos(k) + 8 - i.e. two 8-byte stores.
+__host__ __device__ constexpr int pos16(int k) { return ((k & 1) << 3) | (((k >> 2) & 1) << 2) | (((k >> 3) & 1) << 1) | ((k >> 1) & 1); }
+// position (floats) of natural column c inside a row
+__host__ __device__ constexpr int pcol(int c) { return (c & ~15) | pos16(c & 15); }
+
+// a lane's T consecutive natural columns [col, col + T) of one tile row (col % T == 0): store / load, operand-order (PERM)
+// or natural layout
+template <int T, bool PERM>
+__device__ __forceinline__ void tile_put(float* __restrict__ row, int col, const typename VecOf<T>::type& v) {
+  if constexpr (!PERM) {
+    *reinterpret_cast<typename VecOf<T>::type*>(row + col) = v;
+  } else if constexpr (T == 4) {
+    const int p = pcol(col);
+    *reinterpret_cast<f2v*>(row + p) = f2v{v[0], v[2]};
+    *reinterpret_cast<f2v*>(row + p + 8) = f2v{v[1], v[3]};
+  } else if constexpr (T == 2) {
+    const int p = pcol(col);
+    row[p] = v[0];
+    row[p + 8] = v[1];
+  } else {
+    row[pcol(col)] = v;
+  }
+}
+template <int T, bool PERM>
+__device__ __forceinline__ typename VecOf<T>::type tile_get(const float* __restrict__ row, int col) {
+  using V = typename VecOf<T>::type;
+  if constexpr (!PERM) {
+    return *reinterpret_cast<const V*>(row + col);
+  } else if constexpr (T == 4) {
+    const int p = pcol(col);
+    const f2v a = *reinterpret_cast<const f2v*>(row + p), b = *reinterpret_cast<const f2v*>(row + p + 8);
+    return V{a[0], b[0], a[1], b[1]};
+  } else if constexpr (T == 2) {
+    const int p = pcol(col);
+    return V{row[p], row[p + 8]};
+  } else {
+    return row[pcol(col)];
+  }
+}
+// the four operands of a unit straight out of an operand-order row
+__device__ __forceinline__ void ops_of(const f4v v, float (&o)[4]) { o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w; }
+
 // The four MFMA operands of one 16-k unit out of a lane's float4 (k = 4 g4 + e): operand i of lane group g4 carries
 //   i = 0: k {0,4,1,5}[g4]   i = 1: {2,6,3,7}   i = 2: {8,12,9,13}   i = 3: {10,14,11,15}
 // (v_permlane32_swap a, b: a <- [a.lo | b.lo], b <- [a.hi | b.hi] over the two 32-lane halves)
@@ -193,9 +242,9 @@ struct Fwd16 {
   __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane, Next& nx) {
     const float* ap = tile + (lane & 15) * ld + 4 * (lane >> 4);
     float a[2][4], b[2][T][4];
-    prep(*reinterpret_cast<const f4v*>(ap), a[0]);
+    ops_of(*reinterpret_cast<const f4v*>(ap), a[0]);          // the activation tile is in operand order
 #pragma unroll
-    for (int t = 0; t < T; ++t) prep(ring[0][t], b[0][t]);
+    for (int t = 0; t < T; ++t) prep(ring[0][t], b[0][t]);   // the weights come straight from memory: natural order
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
@@ -213,7 +262,7 @@ struct Fwd16 {
       STEP16_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
       if (j + 1 < NE) {
-        prep(af, a[n]);
+        ops_of(af, a[n]);
 #pragma unroll
         for (int t = 0; t < T; ++t) prep(ring[(j + 1) % DE][t], b[n][t]);
       }
@@ -252,7 +301,7 @@ struct FwdL {
     rs = prs;
     so = (uint32_t)(w_off + (int64_t)wave * 16 * T * K) * 4u;
     vo = (uint32_t)((lane >> 3) * K + 4 * (lane & 7)) * 4u;
-    wr = slot + (lane >> 3) * S + 4 * (lane & 7);
+    wr = slot + (lane >> 3) * S + 16 * ((lane & 7) >> 2) + pos16(4 * (lane & 3));   // operand order: k (4 q ..) -> two pairs
     rd = slot + (lane & 15) * T * S + 4 * (lane >> 4);
   }
   __device__ __forceinline__ void request(int j, int slot) {
@@ -276,7 +325,11 @@ struct FwdL {
     for (int i = 0; i < NLD; ++i) asm volatile("" ::"v"(ring[j % DE][i]));
 #else
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) *reinterpret_cast<f4v*>(wr + 8 * i * S) = ring[j % DE][i];
+    for (int i = 0; i < NLD; ++i) {
+      const f4v v = ring[j % DE][i];
+      *reinterpret_cast<f2v*>(wr + 8 * i * S) = f2v{v.x, v.z};
+      *reinterpret_cast<f2v*>(wr + 8 * i * S + 8) = f2v{v.y, v.w};
+    }
 #endif
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -288,9 +341,9 @@ struct FwdL {
   static __device__ __forceinline__ void make_ops(Ops& o, const Raw& r) {
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      prep(r.a[u], o.a[u]);
+      ops_of(r.a[u], o.a[u]);
 #pragma unroll
-      for (int t = 0; t < T; ++t) prep(r.b[u][t], o.b[u][t]);
+      for (int t = 0; t < T; ++t) ops_of(r.b[u][t], o.b[u][t]);
     }
   }
   template <class Next>
@@ -308,23 +361,36 @@ struct FwdL {
 #pragma unroll
     for (int j = 0; j < NE; ++j) {                      // one scheduling region per stage, see Fwd16::run
       const int c = j & 1, n = c ^ 1;
-      // three sub-regions, in issue order: (1) stage j + 1 into the slot and its fragments requested back, (2) the
-      // MFMAs of stage j - 8 T x 32 cycles of matrix pipe, behind which the LDS round trip of (1) completes - (3) the lane
-      // swaps that turn the fragments into operands.  Left to itself the compiler puts the swaps between the MFMAs,
-      // right behind the ds_reads they wait for: one exposed LDS latency in the middle of every stage.
+      // ONE scheduling region per stage, its instructions interleaved by sched_group_barrier: behind every MFMA of stage j
+      // (32 cycles of matrix pipe each) one LDS operation of stage j + 1 -
+      //     4 T x (MFMA, ds_write_b64)    the staged weights into the slot, operand order
+      //     2 T + 2 x (MFMA, ds_read_b128) the fragments back (LDS operations of a wave execute in order) = the operands
+      // As separate blocks (LDS, MFMAs, swaps) the two waves of a SIMD stayed in phase - both stalled at the issue of their
+      // ds_write_b128 (the VGPR -> LDS path is shared by two SIMDs: 13 cycles per store) with the matrix pipe idle, then
+      // both in their MFMA block: 1600 cycles per stage pair where the pipe needs 1024 (r6_step16_timeline_waves.txt).
       Raw r;
       if (j + 1 < NE) stage_in(r, ap, j + 1);           // (every fragment of stage j was read in the previous region)
-      __builtin_amdgcn_sched_barrier(0);
-      STEP16_PRIO(1);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int t = 0; t < T; ++t) STEP16_MFMA(ops[c].a[u][i], ops[c].b[u][t][i], acc[t]);
-      STEP16_PRIO(0);
-      __builtin_amdgcn_sched_barrier(0);
       if (j + 1 < NE) make_ops(ops[n], r);
+      if (j + 1 < NE) {
+        constexpr int kMfma = 8 * T, kWr = 2 * NLD, kRd = 2 + 2 * T;
+        static_assert(kWr + kRd <= kMfma + 2, "one LDS operation behind (nearly) every MFMA");
+#pragma unroll
+        for (int q = 0; q < kWr; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < kRd; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
       stream_next(*this, nx, j);
     }
     stream_rest<FwdL, Next>(nx);
@@ -358,7 +424,7 @@ struct Bwd {
   __device__ __forceinline__ void run(const float* __restrict__ tile, const int ld, f4v (&acc)[T], int lane, Next& nx) {
     const float* ap = tile + (lane & 15) * ld + 4 * (lane >> 4);
     float a[2][4];
-    prep(*reinterpret_cast<const f4v*>(ap), a[0]);
+    ops_of(*reinterpret_cast<const f4v*>(ap), a[0]);          // the dZ tile is in operand order
 #pragma unroll
     for (int t = 0; t < T; ++t) acc[t] = f4v{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
@@ -375,7 +441,7 @@ struct Bwd {
         for (int t = 0; t < T; ++t) STEP16_MFMA(a[c][i], vget<T>(ring[j % DE][i], t), acc[t]);
       STEP16_PRIO(0);
       __builtin_amdgcn_sched_barrier(0);
-      if (j + 1 < NE) prep(af, a[n]);
+      if (j + 1 < NE) ops_of(af, a[n]);
       stream_next(*this, nx, j);
     }
     stream_rest<Bwd, Next>(nx);
@@ -394,8 +460,9 @@ constexpr size_t lds_floats() {
 }
 
 // acc[t][r] of lane (c16, g4): row 4 g4 + r, column w CW + c16 T + t
-// forward epilogue: elu(acc + bias) -> LDS tile (+ global copy for the weight-gradient launch)
-template <int T, int N>
+// forward epilogue: elu(acc + bias) -> LDS tile, operand order (PERM: a contraction reads it) or natural (the head code
+// reads the last layer's tile by column) (+ global copy, natural, for the weight-gradient launch)
+template <int T, int N, bool PERM>
 __device__ __forceinline__ void fwd_epilogue(const f4v (&acc)[T], const typename VecOf<T>::type bias, float* __restrict__ tile,
                                              float* hg, int64_t M, int64_t r0, int wave, int lane) {
   using V = typename VecOf<T>::type;
@@ -407,34 +474,37 @@ __device__ __forceinline__ void fwd_epilogue(const f4v (&acc)[T], const typename
 #pragma unroll
     for (int t = 0; t < T; ++t) vset<T>(o[r], t, gemm::elu_f(acc[t][r] + vget<T>(bias, t)));
 #pragma unroll
-  for (int r = 0; r < 4; ++r) *reinterpret_cast<V*>(tile + (4 * g4 + r) * ld + col) = o[r];
+  for (int r = 0; r < 4; ++r) tile_put<T, PERM>(tile + (4 * g4 + r) * ld, col, o[r]);
   if (hg != nullptr) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(hg, 0, (int)(M * N * 4), 0x00020000);
 #pragma unroll
     for (int r = 0; r < 4; ++r) bstore<T>(o[r], rs, (uint32_t)(((r0 + 4 * g4 + r) * N + col) * 4));
   }
 }
-// data-gradient epilogue: dZ = acc * elu'(H) with H from the layer's LDS tile; dZ -> the same tile (when a further
-// contraction reads it) and -> global memory
-template <int T, int N, bool TO_TILE>
+// data-gradient epilogue: dZ = acc * elu'(H) with H from the layer's LDS tile (PERM_IN: stored in operand order); dZ -> the
+// same tile in operand order (TO_TILE: a further contraction reads it) and -> global memory.  A wave owns whole 16-column
+// blocks, so a tile that changes layout in place (natural H -> operand-order dZ) only moves values among this wave's own
+// lanes: every H value is read before the first dZ value is written (LDS operations of a wave execute in order).
+template <int T, int N, bool TO_TILE, bool PERM_IN>
 __device__ __forceinline__ void bwd_epilogue(const f4v (&acc)[T], float* __restrict__ tile, float* zg, int64_t M,
                                              int64_t r0, int wave, int lane) {
   using V = typename VecOf<T>::type;
   const int c16 = lane & 15, g4 = lane >> 4, col = wave * 16 * T + c16 * T;
   constexpr int ld = N + kPad;
-  V o[4];
+  V hv[4], o[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const V hv = *reinterpret_cast<const V*>(tile + (4 * g4 + r) * ld + col);
+  for (int r = 0; r < 4; ++r) hv[r] = tile_get<T, PERM_IN>(tile + (4 * g4 + r) * ld, col);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int t = 0; t < T; ++t) {
-      const float hx = vget<T>(hv, t);
+      const float hx = vget<T>(hv[r], t);
       vset<T>(o[r], t, acc[t][r] * (hx > 0.0f ? 1.0f : hx + 1.0f));      // elu'(z) = 1 (z > 0) | elu(z) + 1
     }
-  }
   if (TO_TILE) {
+    if (!PERM_IN) __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) *reinterpret_cast<V*>(tile + (4 * g4 + r) * ld + col) = o[r];
+    for (int r = 0; r < 4; ++r) tile_put<T, true>(tile + (4 * g4 + r) * ld, col, o[r]);
   }
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(zg, 0, (int)(M * N * 4), 0x00020000);
 #pragma unroll
@@ -504,7 +574,11 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
 #pragma unroll
     for (int j = 0; j < XQ; ++j) {
       const int f = tid + j * kThreads, r = f / q4, q = f - r * q4;
-      if (f < kR * q4) *reinterpret_cast<u32x4*>(tX + r * ldx + 4 * q) = xr[j];
+      if (f < kR * q4) {                             // operand order: (k, k + 2) at pos(k), (k + 1, k + 3) eight further
+        float* xp = tX + r * ldx + pcol(4 * q);
+        *reinterpret_cast<u32x2*>(xp) = u32x2{xr[j][0], xr[j][2]};
+        *reinterpret_cast<u32x2*>(xp + 8) = u32x2{xr[j][1], xr[j][3]};
+      }
     }
   }
   // advantage statistics over the minibatch (ppo.py:314-318: mean, unbiased std): wave 4 - idle while waves 0-3 compute
@@ -525,12 +599,12 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
   f4v acc0[T0], acc1[T1], acc2[T2];
   L0.run(tX, ldx, acc0, lane, L1);
   S16_TL(2);
-  fwd_epilogue<T0, N0>(acc0, bias0, t0, a.H[net][0], a.M, r0, wave, lane);
+  fwd_epilogue<T0, N0, true>(acc0, bias0, t0, a.H[net][0], a.M, r0, wave, lane);
   __syncthreads();
   S16_TL(3);
   L1.run(t0, ld0, acc1, lane, L2);
   S16_TL(4);
-  fwd_epilogue<T1, N1>(acc1, bias1, t1, a.H[net][1], a.M, r0, wave, lane);
+  fwd_epilogue<T1, N1, true>(acc1, bias1, t1, a.H[net][1], a.M, r0, wave, lane);
   __syncthreads();
   S16_TL(5);
   // (requested here, one layer ahead of their use, instead of at kernel entry: 14 VGPRs less through layers 0 and 1)
@@ -573,7 +647,7 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
     for (int t = 0; t < T2; ++t) vset<T2>(z, t, 0.0f);
     bwB[i] = k < KH ? *reinterpret_cast<const typename VecOf<T2>::type*>(Wh + k * HL + wave * 16 * T2 + c16 * T2) : z;
   }
-  fwd_epilogue<T2, N2>(acc2, bias2, t2, nullptr, a.M, r0, wave, lane);
+  fwd_epilogue<T2, N2, false>(acc2, bias2, t2, nullptr, a.M, r0, wave, lane);
   __syncthreads();
   S16_TL(7);
 
@@ -749,7 +823,7 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
 #pragma unroll
       for (int t = 0; t < T2; ++t) STEP16_MFMA(ga[i], vget<T2>(bwB[i], t), cb[t]);
     __builtin_amdgcn_wave_barrier();
-    bwd_epilogue<T2, N2, true>(cb, t2, a.dZ[net][2], a.M, r0, wave, lane);
+    bwd_epilogue<T2, N2, true, false>(cb, t2, a.dZ[net][2], a.M, r0, wave, lane);
   }
   __syncthreads();
   S16_TL(10);
@@ -758,13 +832,13 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
   f4v ax1[T1];
   B2.run(t2, ld2, ax1, lane, B1);
   S16_TL(11);
-  bwd_epilogue<T1, N1, true>(ax1, t1, a.dZ[net][1], a.M, r0, wave, lane);
+  bwd_epilogue<T1, N1, true, true>(ax1, t1, a.dZ[net][1], a.M, r0, wave, lane);
   __syncthreads();
   S16_TL(12);
   f4v ax0[T0];
   B1.run(t1, ld1, ax0, lane, nonext);
   S16_TL(13);
-  bwd_epilogue<T0, N0, false>(ax0, t0, a.dZ[net][0], a.M, r0, wave, lane);
+  bwd_epilogue<T0, N0, false, true>(ax0, t0, a.dZ[net][0], a.M, r0, wave, lane);
 
   // ---- scalars of the tile: bias / logstd gradients, diagnostics (rows in fixed order)
   float* ps = g.part_s + (int64_t)prow * NS;
@@ -827,7 +901,11 @@ __global__ __launch_bounds__(step16::kThreads) void step16_fwd_kernel(const Fuse
 #pragma unroll
     for (int j = 0; j < XQ; ++j) {
       const int f = tid + j * kThreads, r = f / q4, q = f - r * q4;
-      if (f < kR * q4) *reinterpret_cast<u32x4*>(tX + r * ldx + 4 * q) = xr[j];
+      if (f < kR * q4) {                             // operand order: (k, k + 2) at pos(k), (k + 1, k + 3) eight further
+        float* xp = tX + r * ldx + pcol(4 * q);
+        *reinterpret_cast<u32x2*>(xp) = u32x2{xr[j][0], xr[j][2]};
+        *reinterpret_cast<u32x2*>(xp + 8) = u32x2{xr[j][1], xr[j][3]};
+      }
     }
   }
   const typename VecOf<T0>::type bias0 = *reinterpret_cast<const typename VecOf<T0>::type*>(P + a.off_b[net][0] + wave * 16 * T0 + c16 * T0);
@@ -840,13 +918,13 @@ __global__ __launch_bounds__(step16::kThreads) void step16_fwd_kernel(const Fuse
   __syncthreads();
   f4v acc0[T0], acc1[T1], acc2[T2];
   L0.run(tX, ldx, acc0, lane, L1);
-  fwd_epilogue<T0, N0>(acc0, bias0, t0, nullptr, a.M, r0, wave, lane);
+  fwd_epilogue<T0, N0, true>(acc0, bias0, t0, nullptr, a.M, r0, wave, lane);
   __syncthreads();
   L1.run(t0, ld0, acc1, lane, L2);
-  fwd_epilogue<T1, N1>(acc1, bias1, t1, nullptr, a.M, r0, wave, lane);
+  fwd_epilogue<T1, N1, true>(acc1, bias1, t1, nullptr, a.M, r0, wave, lane);
   __syncthreads();
   L2.run(t1, ld1, acc2, lane, nonext);
-  fwd_epilogue<T2, N2>(acc2, bias2, t2, nullptr, a.M, r0, wave, lane);
+  fwd_epilogue<T2, N2, false>(acc2, bias2, t2, nullptr, a.M, r0, wave, lane);
   __syncthreads();
   if (a.do_head) fused_head<N2, kR>(a, t2, ld2, net, r0, t0);      // (the first activation tile is free: head weights go there)
 }
