@@ -18,7 +18,8 @@ Solo12, 6 constraint terms (42 columns), 48-d obs, 3x256 MLP;  --workload refere
 (45-d obs, 13 terms / 78 columns, 512/256/128 MLPs).
 
 Scaling (--gpus N > 1): default = WEAK (every rank owns the workload's envs and minibatch share: global minibatch =
-16384 x N).  --workload cfg3 is BASELINE configs[2] as written - 16384 envs and a 16384-sample minibatch GLOBAL, sharded
+16384 x N) - and the same line carries a `strong` record: cfg3 measured by the same process group right behind the weak
+timed region (value, per-rank times, wire time, RCCL world, rank 0's roofline fraction; --no-strong skips it).  --workload cfg3 is BASELINE configs[2] as written - 16384 envs and a 16384-sample minibatch GLOBAL, sharded
 over the ranks - i.e. STRONG scaling of a fixed job.
 """
 from __future__ import annotations
@@ -287,6 +288,70 @@ def time_group_eager(trainer, reps=12, skip=2):
     return float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) * 1e3, len(ev)
 
 
+def strong_record(a, world, rank, dev_index, shared, steps, warmup):
+    """`--gpus N` (N > 1) prints the WEAK line the driver's contract asks for; BASELINE configs[2] - 16384 envs and a
+    16384-row minibatch GLOBAL, sharded over the ranks (solo12/agents/clean_rl_ppo_cfg.py:20; exchange semantics of the
+    reference's only distributed trainer, skrl/ppo.py:534-537) - is a different hyper-parameter set, so the same process
+    group measures it right behind the weak timed region and the line carries it as `strong`: value, per-rank times,
+    serialised wire time, the RCCL world, rank 0's minibatch-group time and roofline fraction.  Every rank runs this."""
+    import contextlib
+    from cat_envs import parallel
+    w = WORKLOADS["cfg3"]
+    with contextlib.redirect_stdout(sys.stderr):
+        env, tr, cfg = build("cfg3", a.seed + rank, dev_index, None, world, rank, {})
+
+    def barrier():
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(warmup):
+        tr.run_iteration(log=True)
+    tr.time_phases = True
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.run_iteration(log=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    phases = tr.phase_summary()
+    tr.time_phases = False
+    times = [None] * world
+    torch.distributed.all_gather_object(times, dt)
+    dt = max(times)
+    # serialised wire time of one iteration (as the weak record's `comm`): un-graphed, un-overlapped pass
+    g_was, ov_was = tr.graph_update, tr.grad_overlap
+    tr.graph_update = False
+    if ov_was:
+        tr.grad_overlap = tr.nat.set_grad_overlap(False)
+    tr.run_iteration(log=True)
+    barrier()
+    parallel.comm_timing_begin()
+    tr.run_iteration(log=True)
+    comm = parallel.comm_timing_end()
+    barrier()
+    tr.graph_update = g_was
+    rec = None
+    if rank == 0:
+        grad_us, n_timed = time_group_eager(tr)        # (gradient buckets are off: no collective inside the call)
+        macs = fwd_macs(w["obs_dim"], w["hidden"])
+        flops = 3 * 2 * macs * tr.M
+        rec = {"workload": "cfg3: " + w["desc"], "scaling": "strong", "value": tr.n_envs_global * w["num_steps"] * steps / dt,
+               "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * dt / steps,
+               "per_rank_ms": {"min": 1e3 * min(times) / steps, "max": 1e3 * max(times) / steps,
+                               "by_rank": [1e3 * x / steps for x in times]},
+               "envs_per_gpu": tr.N, "envs_total": tr.n_envs_global, "minibatch_per_gpu": tr.M, "global_minibatch": tr.M * world,
+               "rccl_world": tr.nat.comm_world if parallel.native_comm_active() else (world if not shared else 0),
+               "comm_ms_per_iteration": comm["ms"], "collectives_per_iteration": comm["calls"],
+               "phases_device_ms": phases, "graph_update": tr.graph_update, "graph_fallback": tr.graph_fallback,
+               "roofline": {"bound": "mfma", "rank": 0, "avg_launch_us": grad_us, "launches_timed": n_timed,
+                            "achieved": flops / grad_us / 1e6, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flops / grad_us / 1e6 / MFMA_F32_PEAK_TFLOPS,
+                            "kernel": f"catppo_ppo_minibatch_grad_packed per {tr.M}-sample minibatch (rank 0; every rank runs the same shapes)"}}
+    if ov_was:
+        tr.grad_overlap = tr.nat.set_grad_overlap(getattr(tr, "_grad_overlap_mode", True))
+    barrier()
+    return rec
+
+
 def secondary_record(a, w, dev_index, steps, warmup):
     """The same workload with split-bf16 GEMM operands (`mlp_precision="bf16x3"`: hi/lo bf16 planes, three bf16 MFMAs per
     product, ~16 mantissa bits - wider than the TF32 arithmetic the reference enables for these GEMMs,
@@ -395,6 +460,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary record (the same workload with split-bf16 GEMM operands, measured AFTER the "
                          "timed region of the fp32 headline; single process, fp32 workloads only)")
+    ap.add_argument("--no-strong", action="store_true",
+                    help="--gpus N > 1 with a weak workload: skip the `strong` record (cfg3 measured in the same process group "
+                         "behind the weak timed region)")
     ap.add_argument("--shard-of", type=int, default=0, metavar="W",
                     help="single process, no collectives: run ONE rank's share of a strong-scaling workload as if the "
                          "world had W ranks (compute side of the scaling curve on a one-GPU box)")
@@ -552,6 +620,10 @@ def main():
         if ov_was:
             trainer.grad_overlap = nat.set_grad_overlap(getattr(trainer, '_grad_overlap_mode', True))
 
+    strong = None
+    if world > 1 and not w.get("strong") and not a.no_strong:
+        strong = strong_record(a, world, rank, dev_index, shared, max(2, a.steps // 2), max(1, a.warmup // 2))
+
     if rank == 0:
         M = trainer.M
         if trainer.graph_update or not ev:         # eager replay of the group on the data of the last iteration
@@ -665,6 +737,8 @@ def main():
             out["secondary"] = secondary_record(a, w, dev_index, max(3, a.steps // 2), max(2, a.warmup // 2))
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, trainer, env, agent_cfg)
+        if strong is not None:
+            out["strong"] = strong
     else:
         out = None
     if torch.distributed.is_initialized():

@@ -80,3 +80,11 @@ def test_bench_gpus_2_starts_two_ranks_itself(tmp_path):
         assert d["ranks_share_gpus"] is False and d["config"]["rccl_world"] == 2
         assert d["config"]["graph_fallback"] is None or isinstance(d["config"]["graph_fallback"], str)
     assert d["value"] > 0 and abs(d["value"] - d["config"]["envs_total"] * 24 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-3 * d["value"]
+    # round 6: the weak line carries BASELINE configs[2] as a `strong` record of the same process group
+    st = d["strong"]
+    assert st["scaling"] == "strong" and st["workload"].startswith("cfg3") and st["envs_total"] == 16384
+    assert st["envs_per_gpu"] == 8192 and st["minibatch_per_gpu"] == 8192 and st["global_minibatch"] == 16384
+    assert st["value"] > 0 and abs(st["value"] - 16384 * 24 * st["steps"] / (st["ms_per_step"] * st["steps"] * 1e-3)) < 1e-3 * st["value"]
+    assert len(st["per_rank_ms"]["by_rank"]) == 2 and st["comm_ms_per_iteration"] > 0
+    assert st["collectives_per_iteration"] >= 24 + 5 * 24 and 0 < st["roofline"]["frac"] < 1
+    assert st["rccl_world"] == d["config"]["rccl_world"]
