@@ -280,7 +280,10 @@ def _host_staged(t: torch.Tensor, group) -> bool:
     """device tensor on a process group whose backend has no device transport here (gloo: the CPU tests' backend,
     and the way two ranks share ONE GPU in the 2-rank trainer test - RCCL refuses two ranks on one device): the
     operand takes a round trip through host memory.  Correct, deterministic and slow; never the production transport."""
-    return t.is_cuda and dist.get_backend(group) == "gloo" and _device_fallback_group is None
+    # decided per group (ADVICE r5): stage through host memory unless the group that will actually carry `t` - the
+    # caller's, or the nccl fallback that stands in for the gloo WORLD group - has a device transport.  (A device operand
+    # on a gloo SUB-group, e.g. a custom obs_group / dist_group, used to go to gloo unstaged once the fallback existed.)
+    return t.is_cuda and dist.get_backend(_torch_group(t, group)) == "gloo"
 
 
 def _torch_group(t: torch.Tensor, group):

@@ -661,6 +661,16 @@ class PPOTrainer:
             nat.adv_moments_keyed(b_adv, self.state, E, B, M, self._advp_all, self._adv_mom)
             parallel.allreduce_sum_(self._adv_mom)
             nat.adv_stats(self._adv_mom, E * n_mb, self._adv_stats_all)
+        # trace_params (tests: the branch-flip analysis of tests/test_gpu_parity_sizes.py): the flat parameters after every
+        # optimiser step of this update phase, [E * n_mb, n_flat] (device-to-device copies in stream order)
+        trace = None
+        if getattr(self, "trace_params", False):
+            if getattr(self, "param_trace", None) is None or self.param_trace.shape[0] != E * n_mb:
+                self.param_trace = torch.empty(E * n_mb, a.layout.n_flat, device=self.device)
+            trace = self.param_trace
+            self.param_trace_start = a.flat.clone()
+            # (and what this update phase reads: the next rollout's first rows overwrite the buffers' step 0 before a test looks)
+            self.trace_batch = dict(obs=b_obs.clone(), actions=b_act.clone(), logprobs=b_logp.clone(), values_n=b_val.clone())
         for epoch in range(E):
             rec = self.perm_rec[epoch] if self.perm_rec is not None else None
             nat.ppo_gather_ex(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, B, M, self._x_g, self._act_g,
@@ -684,6 +694,8 @@ class PPOTrainer:
                                                   self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
                                                   vmean, vvar, adv_stats, self.grad, self.diag, self.exp_avg,
                                                   self.exp_avg_sq, c.max_grad_norm, 0.9, 0.999, 1e-5, self.state)
+                    if trace is not None:
+                        trace[epoch * n_mb + k].copy_(a.flat)
                     continue
                 nat.ppo_minibatch_grad_packed(a.shape, self.hp, a.flat, self._x_g[start:], self._act_g[start:],
                                               self._scal_g[4 * start:], self._advp_g[2 * k * self._parts:], m,
@@ -692,6 +704,8 @@ class PPOTrainer:
                     parallel.allreduce_sum_(self.grad)          # RCCL SUM of the flat gradient over xGMI
                 nat.clip_adam_dev(a.flat, self.grad, self.exp_avg, self.exp_avg_sq, a.layout.n_flat,
                                   c.max_grad_norm, 0.9, 0.999, 1e-5, self.state)
+                if trace is not None:
+                    trace[epoch * n_mb + k].copy_(a.flat)
             if self.lr_schedule == "adaptive":
                 # KL-adaptive learning rate after every epoch (skrl/ppo.py:558-567), entirely on the device
                 nat.kl_mean(self.state, self.diag, self.kl_buf)
@@ -712,18 +726,26 @@ class PPOTrainer:
             perms = [perm_fn(e) for e in range(E)]
         elif self.rng == "torch":
             perms = [torch.randperm(B, device=self.device) for e in range(E)]
-        if self.graph_update and perms is None and not self.record_noise and self._eager_updates_left > 0:
+        tracing = bool(getattr(self, "trace_params", False))      # (a traced update phase runs eagerly)
+        if self.graph_update and perms is None and not self.record_noise and not tracing and self._eager_updates_left > 0:
             # env-sharded runs: the FIRST update phase runs eagerly, so that RCCL's first collectives of every size
             # (channel set-up, lazily loaded kernels, possibly allocations) happen outside a stream capture
             self._eager_updates_left -= 1
-        elif self.graph_update and perms is None and not self.record_noise:
+        elif self.graph_update and perms is None and not self.record_noise and not tracing:
             if self._graph_id is not None:
                 try:
                     self.nat.graph_launch(self._graph_id)
                     self.adam_step += self._graph_steps
                     return
-                except RuntimeError:                             # workspace grew: the graph was dropped
+                except RuntimeError as e:                        # workspace grew: the graph was dropped
                     self._graph_id = None
+                    if parallel.active() and self.world > 1:
+                        #  the re-capture below ends in a vote (all_gather_object) that only re-capturing ranks
+                        # enter: peers whose replay succeeded are already in the next rollout's collectives, so a rank
+                        # that loses its graph alone must not walk into that vote - it fails loudly instead of hanging
+                        raise RuntimeError(f"rank {self.rank}: replay of the captured update phase failed ({e}) in an "
+                                           f"env-sharded run of {self.world} ranks; re-capturing on one rank would wait in a "
+                                           "vote its peers never join") from e
             try:
                 self.nat.graph_begin()
                 try:

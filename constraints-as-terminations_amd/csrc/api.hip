@@ -69,6 +69,7 @@ extern "C" void catppo_destroy(catppo_ctx* ctx) {
   for (auto& e : ctx->ev_fork)
     if (e) (void)hipEventDestroy(e);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  if (ctx->ev_tail) (void)hipEventDestroy(ctx->ev_tail);
   (void)hipSetDevice(cur);
   delete ctx;
 }

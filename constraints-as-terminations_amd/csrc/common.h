@@ -21,6 +21,7 @@ struct catppo_ctx {
   bool use_side = false;     // CATPPO_SIDE_STREAM=1 forks the weight-gradient GEMMs (measured slower)
   hipEvent_t ev_fork[CATPPO_MAX_HIDDEN + 1] = {};
   hipEvent_t ev_join = nullptr;
+  hipEvent_t ev_tail = nullptr;     // rollout.hip: orders another stream behind a deferred post tail (created on first use)
   // hipGraphs captured through catppo_graph_begin / _end (index = graph id; destroyed slots are null)
   static constexpr int kMaxGraphs = 64;
   hipGraphExec_t graphs[kMaxGraphs] = {};

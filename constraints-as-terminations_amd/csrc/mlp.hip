@@ -939,7 +939,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         px.op[net].aux = w.H[net][l - 1];
       }
       if (pair) {
-        launch_dw_dx_pair(pw, px, s, bf16);
+        launch_dw_dx_pair(pw, px, s, bf16, ctx->n_cu);
         catppo_plan_note(ctx, "layer %d weight gradient (%d x %d, %d splits of %d rows) + data gradient (%lld x %d, k = %d): "
                          "gemm_pair_kernel, ONE launch%s", l, out, in, splits, per, (long long)M, in, out,
                          M <= kSmallRows ? " [<= 4096 rows: 64x64 weight-gradient tiles]" : "");

@@ -243,14 +243,14 @@ void launch_pair_tiles(const Params& pw, const Params& px, hipStream_t s, int pr
 // workgroups of the 128x128 choice: 2048 rows, 256x512 layer: 35 -> 27 us for the pair) and the forward GEMMs walk
 // the contraction in 64-wide slabs (4x fewer round trips; 112 -> 100 us per optimiser step together; measured with
 // CATPPO_DW_SMALL_TILE / CATPPO_SMALL_BK, which remain as switches).
-void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, int prec) {
+void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, int prec, int n_cu = 256) {
   static const int small_tile = env_int("CATPPO_DW_SMALL_TILE", 1);
   // Round 5: a weight gradient whose 128x128 tiling yields fewer long workgroups than there are CUs (a 128-wide layer - the
   // reference's last hidden layer: 2 tiles x 2 networks x 32 splits = 128 on 256 CUs) takes 64x64 tiles instead (512
   // shorter workgroups, same splits, same contraction order per element: bit-identical): the reference's layer-2 pair
   // 60.1 -> 50.6 us, update phase 11.70 -> 11.51 ms (profiles/r5_ab_dw_fill.txt).  CATPPO_DW_FILL=0: the 128x128 tiling.
   static const int dw_fill = env_int("CATPPO_DW_FILL", 1);
-  const bool underfilled = dw_fill && tiles_of<128, 128>(pw) * pw.nets * pw.splits < 256;
+  const bool underfilled = dw_fill && tiles_of<128, 128>(pw) * pw.nets * pw.splits < n_cu;      // (the device's CU count)
   const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256 &&   // launch_gemm_auto's rule for EPI_PARTIAL
                    !(px.I <= kSmallRows && small_tile) && !underfilled;
   const bool wide = px.J >= 128;

@@ -840,11 +840,18 @@ int flush_post_tail(catppo_ctx* ctx, hipStream_t stream) {
   PostArgs tl;
   memcpy(&tl, ctx->post_tail_args, sizeof(tl));
   // the tail belongs behind the post launch: on the stream that launch went to, whatever the caller passes now
-  (void)stream;
-  hipLaunchKernelGGL(rollout_post_tail_kernel, dim3(1), dim3(kThreads), 0, static_cast<hipStream_t>(ctx->post_tail_stream),
-                     tl, ctx->post_tail_nblk);
+  hipStream_t ts = static_cast<hipStream_t>(ctx->post_tail_stream);
+  hipLaunchKernelGGL(rollout_post_tail_kernel, dim3(1), dim3(kThreads), 0, ts, tl, ctx->post_tail_nblk);
   ctx->post_tail_pending = false;
   CATPPO_CHECK_LAUNCH(ctx);
+  //  a caller on ANOTHER stream is about to enqueue work that reads what the tail publishes (running maxima,
+  // normaliser state): order that stream behind the tail instead of leaving it to the caller
+  if (stream != ts) {
+    if (ctx->ev_tail == nullptr && hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming) != hipSuccess)
+      return catppo_fail(ctx, CATPPO_E_HIP, "flush_post_tail: hipEventCreate failed");
+    if (hipEventRecord(ctx->ev_tail, ts) != hipSuccess || hipStreamWaitEvent(stream, ctx->ev_tail, 0) != hipSuccess)
+      return catppo_fail(ctx, CATPPO_E_HIP, "flush_post_tail: cannot order the calling stream behind the deferred tail");
+  }
   return CATPPO_OK;
 }
 

@@ -286,7 +286,9 @@ def ppo_minibatch_loss(agent: AgentOracle, mb_obs, mb_actions, mb_logprobs, mb_a
             margin = torch.minimum(margin, ((newvalue - mb_values_n).abs() - cfg["clip_coef"]).abs().min())
     return loss, {"pg_loss": pg_loss.detach(), "v_loss": v_loss.detach(), "entropy": ent.detach(),
                   "loss": loss.detach(), "approx_kl": approx_kl, "old_approx_kl": old_approx_kl,
-                  "clipfrac": clipfrac, "clip_boundary_margin": margin}
+                  "clipfrac": clipfrac, "clip_boundary_margin": margin,
+                  # per-sample quantities the clip branches depend on (PPOOracle.trace: the branch-flip test)
+                  "ratio": ratio.detach(), "newvalue_n": newvalue.detach()}
 
 
 class PPOOracle:
@@ -372,6 +374,8 @@ class PPOOracle:
         B, M = T * N, c["minibatch_size"]
         sums = {"pg_loss": 0.0, "entropy": 0.0, "v_loss": 0.0, "loss": 0.0}
         last_stats = None
+        if getattr(self, "trace", False):
+            self.step_trace = []          # (of the current iteration)
         for epoch in range(c["updates_epochs"]):
             inds = torch.randperm(B) if perm_fn is None else perm_fn(epoch)
             # a list of index tensors = the minibatches themselves (env-sharded runs: global minibatch k is the
@@ -391,6 +395,14 @@ class PPOOracle:
                 torch.nn.utils.clip_grad_norm_(self.params, c["max_grad_norm"])
                 self.opt.step()
                 last_stats = st
+                if getattr(self, "trace", False):
+                    # per optimiser step: the minibatch, what its clip branches were decided on (evaluated at the
+                    # parameters BEFORE the step) and the parameters AFTER it, reference registration order
+                    if not hasattr(self, "step_trace"):
+                        self.step_trace = []
+                    self.step_trace.append(dict(mb=mb.clone(), ratio=st["ratio"].clone(), newvalue_n=st["newvalue_n"].clone(),
+                                                old_values_n=b_values[mb].clone(),
+                                                params=torch.cat([q_.detach().reshape(-1) for q_ in self.agent.parameters()]).clone()))
         t3 = time.perf_counter()
         self.timers["rollout"] += t1 - t0
         self.timers["gae"] += t2 - t1

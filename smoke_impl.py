@@ -39,7 +39,7 @@ def make_cfgs(num_envs, num_steps, minibatch, epochs, iters, hidden=(512, 256, 1
 
 
 def run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=1, hidden=(512, 256, 128), six_terms=True,
-             seed=42, obs_dim=45, agent_overrides=None, randomness="inject"):
+             seed=42, obs_dim=45, agent_overrides=None, randomness="inject", trace=False):
     """returns (trainer, oracle, per-iteration oracle outputs).
 
     randomness="inject": action noise and minibatch permutations come from a numpy RandomState and are handed to
@@ -67,6 +67,8 @@ def run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=1, hidden=
     rs = np.random.RandomState(seed)
     outs = []
     B = num_envs * num_steps
+    if trace:        # parameters after every optimiser step on both sides (branch_flip_report below)
+        trainer.trace_params, orc.trace = True, True
     for it in range(iters):
         if randomness == "device":
             trainer.record_noise = True
@@ -85,6 +87,71 @@ def run_pair(num_envs=64, num_steps=8, minibatch=256, epochs=2, iters=1, hidden=
                                       perm_fn=lambda e: torch.from_numpy(perms[e]), actions_fn=lambda s: acts[s]))
     torch.cuda.synchronize()
     return trainer, orc, outs
+
+
+def logical_params(agent, flat):
+    """the parameters of one flat buffer (catppo_mlp_layout: padded first-layer rows, aligned segments) in the reference's
+    registration order - actor_logstd, critic.{0,2,..}.{weight,bias}, actor_mean.{...} - as one CPU vector"""
+    lay, L = agent.layout, agent.shape.n_hidden
+    flat = flat.detach().cpu()
+    out = [flat[lay.off_logstd:lay.off_logstd + agent.act_dim]]
+    dims = [agent.obs_dim, *agent.hidden]
+    for net in (0, 1):
+        for l in range(L + 1):
+            out_f = (1 if net == 0 else agent.act_dim) if l == L else agent.hidden[l]
+            in_f, ld = dims[l], lay.in_dim[l]
+            out.append(flat[lay.off_w[net][l]:lay.off_w[net][l] + out_f * ld].view(out_f, ld)[:, :in_f].reshape(-1))
+            out.append(flat[lay.off_b[net][l]:lay.off_b[net][l] + out_f])
+    return torch.cat(out)
+
+
+def branch_flip_report(trainer, orc, tight_bar):
+    """Why did the parameters of the last (traced) iteration leave the tight bar?  cleanrl/ppo.py:320-341: the gradients of
+    the clipped surrogate and of the clipped value loss jump where |ratio - 1| = clip / |newvalue - old value| = clip.
+    Finds the first optimiser step k after which device and oracle parameters differ by >= tight_bar, evaluates the clip
+    branches of that step's minibatch ON THE DEVICE (catppo_policy_act with the device's parameters before step k and the
+    minibatch's own actions -> log-prob, value -> ratio, value difference), compares them with the oracle's branches of
+    the same step, and reports the samples that sit on different sides together with the oracle's distance of those
+    samples to the boundary.  Needs run_pair(trace=True)."""
+    from cat_envs import native
+    agent, nat, cfg = trainer.agent, trainer.nat, trainer.cfg
+    steps = orc.step_trace
+    n = len(steps)
+    assert trainer.param_trace.shape[0] == n, (trainer.param_trace.shape, n)
+    errs = [float((logical_params(agent, trainer.param_trace[k]).double() - steps[k]["params"].double()).abs().max())
+            for k in range(n)]
+    bad = [k for k in range(n) if errs[k] >= tight_bar]
+    if not bad:
+        return dict(first_step=None, errs=errs)
+    k = bad[0]
+    theta = trainer.param_trace[k - 1] if k > 0 else trainer.param_trace_start
+    mb = steps[k]["mb"].to(trainer.device)
+    tb = trainer.trace_batch                      # the update phase's own inputs (snapshot taken when it started)
+    x = tb["obs"][mb].float().contiguous()
+    act = tb["actions"][mb].float().contiguous()
+    M = int(mb.numel())
+    a_out, lp, val = torch.empty(M, trainer.A, device=trainer.device), torch.empty(M, device=trainer.device), torch.empty(M, device=trainer.device)
+    nat.mlp_reserve(agent.shape, M)
+    nat.policy_act(agent.shape, theta.contiguous(), x, M, None, a_out, lp, val, given_action=act)
+    torch.cuda.synchronize()
+    clip = float(cfg.clip_coef)
+    ratio_d = (lp - tb["logprobs"][mb].float()).exp().cpu()
+    nv_d = ((val - agent.value_rms.running_mean) / torch.sqrt(agent.value_rms.running_var + 1e-8)).cpu()
+    dl_d = nv_d - tb["values_n"][mb].float().cpu()
+    ratio_o, dl_o = steps[k]["ratio"], steps[k]["newvalue_n"] - steps[k]["old_values_n"]
+
+    def code(v, centre):
+        return (v < centre - clip).long() + 2 * (v > centre + clip).long()
+    pg_diff = code(ratio_d, 1.0) != code(ratio_o, 1.0)
+    v_diff = (code(dl_d, 0.0) != code(dl_o, 0.0)) if bool(cfg.clip_vloss) else torch.zeros_like(pg_diff)
+    m_pg = ((ratio_o - 1.0).abs() - clip).abs()
+    m_v = (dl_o.abs() - clip).abs()
+    margins = torch.cat([m_pg[pg_diff], m_v[v_diff]])
+    return dict(first_step=k, n_steps=n, err_before=errs[k - 1] if k > 0 else 0.0, err_at=errs[k], errs=errs,
+                flipped_surrogate=int(pg_diff.sum()), flipped_value=int(v_diff.sum()),
+                max_margin_of_flipped=float(margins.max()) if margins.numel() else None,
+                max_device_oracle_ratio_diff=float((ratio_d - ratio_o).abs().max()),
+                max_device_oracle_value_diff=float((dl_d - dl_o).abs().max()))
 
 
 def compare(trainer, orc, out, tol_scale=1.0, check=True):

@@ -1,4 +1,4 @@
-"""Achieved parity errors of the config-size GPU tests, written to profiles/r5_parity.json (round 4: r4_parity.json) (the
+"""Achieved parity errors of the config-size GPU tests, written to profiles/r6_parity.json (round 4: r4_parity.json) (the
 whole-iteration tests printed their errors and threw them away).  One entry per test name: max abs errors per tensor,
 sizes, seed.  The file is merged, not overwritten, so one pytest run (or several gpurun calls) accumulate into it; on
 the GPU box it is written under gpurun_out/ as well so that it travels back."""
@@ -6,11 +6,13 @@ import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PATHS = [os.path.join(ROOT, "profiles", "r5_parity.json"), os.path.join(ROOT, "gpurun_out", "r5_parity.json")]
+PATHS = [os.path.join(ROOT, "profiles", "r6_parity.json"), os.path.join(ROOT, "gpurun_out", "r6_parity.json")]
 
 
 def record(name, errors, sizes=None, seed=None, note=None):
-    entry = {"errors": {k: float(v) for k, v in errors.items()}, "sizes": sizes, "seed": seed}
+    def num(v):
+        return v if isinstance(v, (list, str)) or v is None else float(v)
+    entry = {"errors": {k: num(v) for k, v in errors.items()}, "sizes": sizes, "seed": seed}
     if note:
         entry["note"] = note
     for path in PATHS:

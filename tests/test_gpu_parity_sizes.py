@@ -40,28 +40,51 @@ BARS = {
 # (one sample is ~1 % of the NET critic gradient of a 16384-row minibatch: the per-sample terms largely cancel), and from
 # that optimiser step on the two trajectories differ by 1e-5 .. 1e-4 instead of 1e-7.  Round 5 met this at cfg4 (step 9
 # of 24, profiles/r5_cfg4_branch_flip.txt) when the head products of fwd_head_kernel moved to another MFMA shape - a
-# 1e-7 change of the value head, bit-reproducible, 3e-8 away from the old kernel when no sample sits on a boundary.  The
-# oracle reports the closest approach of any sample to a boundary (`clip_boundary_margin`); only if that is below the
-# noise level may the parameters use the bar of rounds 1-2 instead of the tight one.
-BOUNDARY_NOISE = 1e-5
+# 1e-7 change of the value head, bit-reproducible, 3e-8 away from the old kernel when no sample sits on a boundary.
+# Round 6: the looser bar is no longer granted on the oracle's say-so ("some sample came
+# close").  Both sides record their parameters after EVERY optimiser step; when the tight bar fails the test finds the
+# first step after which they differ by more than it, has the DEVICE evaluate that step's minibatch (log-prob and value
+# under the device's parameters before the step -> ratio, value difference: smoke_impl.branch_flip_report) and demands
+#   (1) until that step the parameters agreed within the tight bar,
+#   (2) at least one sample of that minibatch sits on different sides of a clip boundary on device and oracle,
+#   (3) every such sample is closer to the boundary (in the oracle's arithmetic) than device and oracle disagree about
+#       that per-sample quantity AT THAT STEP - i.e. the flip is explained by the measured disagreement, which itself
+#       must stay small (PER_SAMPLE_DISAGREEMENT_CAP: the parameters differ by < 1.2e-5 there, the value head sums 256
+#       of them).  What the first run of this analysis showed at cfg4 (profiles/r6_parity.json): no sample sits "1e-6
+#       from a boundary" - the parameter distance creeps to 1.0e-5 over nine steps of Adam on rounding-level gradient
+#       differences, the normalised values then disagree by 3.6e-4, and a sample 9e-5 from the value-clip boundary flips.
+# Only then may the parameters use the bar of rounds 1-2; the record names the step, the flipped samples and both numbers.
+PER_SAMPLE_DISAGREEMENT_CAP = 1e-3
 PARAMS_BAR_AFTER_A_BRANCH_FLIP = 4e-4
+BOUNDARY_NOISE = 2e-6          # device / oracle disagreement of ratio and value when the parameters are equal (machinery test)
 
 
 def _iteration(name=None, bars=None, **kw):
     import parity_record
     import smoke_impl
-    trainer, orc, outs = smoke_impl.run_pair(**kw)
+    trainer, orc, outs = smoke_impl.run_pair(trace=True, **kw)
     rep = smoke_impl.compare(trainer, orc, outs[-1], check=False)
     print(name, kw, rep)
     b = dict(BARS["default"], **(BARS.get(name) or {}), **(bars or {}))
     assert rep["rewards"] == 0.0 and rep["dones"] == 0.0, rep          # termination masks are bit-exact
     margin = float(getattr(orc, "clip_boundary_margin", float("inf")))
-    if rep["params"] >= b["params"] and margin < BOUNDARY_NOISE:
-        print(f"{name}: a sample came within {margin:.2e} of a clip boundary (noise level {BOUNDARY_NOISE:.0e}): parameter bar "
-              f"{PARAMS_BAR_AFTER_A_BRANCH_FLIP:.0e} instead of {b['params']:.1e}")
+    flip = None
+    if rep["params"] >= b["params"]:
+        flip = smoke_impl.branch_flip_report(trainer, orc, b["params"])
+        flip_rec = {k: v for k, v in flip.items() if k != "errs"}
+        print(f"{name}: parameters left the {b['params']:.1e} bar - per-step analysis: {flip_rec}")
+        assert flip["first_step"] is not None, ("the per-step traces do not show the divergence the final parameters do", rep)
+        assert flip["err_before"] < b["params"], flip_rec                                     # (1)
+        n_flipped = flip["flipped_surrogate"] + flip["flipped_value"]
+        assert n_flipped >= 1, ("parameters diverged without a clip-branch disagreement: not a boundary effect", flip_rec)   # (2)
+        disagreement = max(flip["max_device_oracle_ratio_diff"] if flip["flipped_surrogate"] else 0.0,
+                           flip["max_device_oracle_value_diff"] if flip["flipped_value"] else 0.0)
+        assert flip["max_margin_of_flipped"] <= disagreement < PER_SAMPLE_DISAGREEMENT_CAP, flip_rec              # (3)
+        flip["errs_up_to_the_step"] = [float(f"{e:.3e}") for e in flip["errs"][:flip["first_step"] + 2]]
         b["params"] = PARAMS_BAR_AFTER_A_BRANCH_FLIP
     if name:
-        parity_record.record(name, dict(rep, clip_boundary_margin=margin, params_bar=b["params"]),
+        extra = {} if flip is None else {f"branch_flip.{k}": v for k, v in flip.items() if k != "errs"}
+        parity_record.record(name, dict(rep, clip_boundary_margin=margin, params_bar=b["params"], **extra),
                              sizes={k: (list(v) if isinstance(v, tuple) else v) for k, v in kw.items()
                                     if k != "agent_overrides"}, seed=kw.get("seed", 42))
     for k, bar in b.items():
@@ -314,3 +337,25 @@ def test_set_term_cfg_with_the_same_object_after_an_in_place_edit_acts_on_the_ne
     for _ in range(70):
         env.step(act)
     assert float(cm.cat._p_cstr[:, col0:col0 + 12].max()) > -50.0
+
+
+def test_branch_flip_analysis_sees_the_same_per_sample_quantities_on_both_sides():
+    """the machinery behind the looser parameter bar, exercised where nothing flips: a 256-env iteration with per-step
+    traces; asked about an absurdly tight bar (1e-9) the report names the first optimiser step, and the device's
+    re-evaluation of that minibatch (catppo_policy_act under the traced parameters) agrees with the oracle's ratio /
+    value difference to BOUNDARY_NOISE - the disagreement level the flip criterion (3) is calibrated on."""
+    import parity_record
+    import smoke_impl
+    trainer, orc, outs = smoke_impl.run_pair(num_envs=256, num_steps=24, minibatch=2048, epochs=3, iters=1, hidden=(256, 256, 256),
+                                             six_terms=True, obs_dim=48, trace=True)
+    rep = smoke_impl.compare(trainer, orc, outs[-1], check=False)
+    assert rep["params"] < BARS["default"]["params"], rep
+    assert smoke_impl.branch_flip_report(trainer, orc, BARS["default"]["params"])["first_step"] is None
+    flip = smoke_impl.branch_flip_report(trainer, orc, 1e-9)
+    assert flip["first_step"] is not None and flip["n_steps"] == 9 and len(flip["errs"]) == 9
+    assert max(flip["errs"]) == pytest.approx(rep["params"], rel=1e-6) or max(flip["errs"]) >= rep["params"]
+    assert flip["max_device_oracle_ratio_diff"] < BOUNDARY_NOISE and flip["max_device_oracle_value_diff"] < BOUNDARY_NOISE, flip
+    if flip["flipped_surrogate"] + flip["flipped_value"]:
+        assert flip["max_margin_of_flipped"] < BOUNDARY_NOISE, flip
+    parity_record.record("branch_flip_machinery_256x24", {k: v for k, v in flip.items() if k != "errs"},
+                         sizes=dict(num_envs=256, num_steps=24, minibatch=2048, epochs=3), seed=42)
