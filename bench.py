@@ -206,7 +206,7 @@ def pmc_traffic(workload, tag):
 
 
 GROUP_KERNELS = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel",
-                 "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel")
+                 "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel", "step16_kernel", "dw_multi_kernel")
 
 
 def profiled_group_us(workload, tag):
@@ -459,7 +459,7 @@ def main():
                          "the bf16 peak).  bf16 = operands rounded to bf16 (BASELINE config 5): NOT a parity mode")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE",
                     help="PPO cfg override, e.g. --set graph_update=True --set rng=torch --set fused_rollout=False")
-    ap.add_argument("--profile-tag", default="r5", help="prefix of the PMC / kernel-trace summaries under profiles/")
+    ap.add_argument("--profile-tag", default="r6", help="prefix of the PMC / kernel-trace summaries under profiles/")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary record (the same workload with split-bf16 GEMM operands, measured AFTER the "
                          "timed region of the fp32 headline; single process, fp32 workloads only)")
@@ -736,6 +736,24 @@ def main():
         }
         # (--no-cpu-baseline = the diagnostic form the A/B and profiling scripts use: no secondary record either, so that a
         # kernel trace of that command holds the kernels of ONE precision)
+        if prec == "bf16":
+            # BASELINE configs[4] (bf16 MFMA operands): the matrix work shrinks 16x while every activation still crosses HBM
+            # in fp32 - the group is HBM-bound, and its roofline object says so.  Algorithmic bytes of one
+            # minibatch group = a layer-wise step that moves every tensor once each way: the gathered
+            # inputs, every hidden activation written and read back, every dZ above the first layer written and read back.
+            hid = list(w["hidden"])
+            act_b = M * sum(hid) * 4 * 2
+            dz_b = M * sum(hid[1:]) * 4 * 2
+            alg_bytes = 2 * act_b + 2 * dz_b + M * (trainer.Dp + trainer.A + 4) * 4
+            mf = out["roofline"]
+            out["roofline"] = {"bound": "hbm", "kernel": mf["kernel"], "achieved": alg_bytes / grad_us / 1e3, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": alg_bytes / grad_us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes,
+                               "traffic": traffic, "traffic_GBps": None if not traffic else traffic / grad_us / 1e3,
+                               "hbm_frac": None if not traffic else traffic / grad_us / 1e3 / HBM_PEAK_GBPS,
+                               "avg_launch_us": grad_us, "launches_timed": n_timed, "timed": mf["timed"],
+                               "traffic_source": traffic_src, "traffic_note": traffic_note, "csrc_hash": mf["csrc_hash"],
+                               "mfma": {k: mf[k] for k in ("achieved", "peak", "unit", "frac", "algorithmic_tflops", "executed_flops",
+                                                          "flops_per_launch", "dominant_kernel_us_profiled", "frac_profiled")}}
         if world == 1 and prec == "fp32" and not a.no_secondary and not a.no_cpu_baseline and a.shard_of == 0:
             out["secondary"] = secondary_record(a, w, dev_index, max(3, a.steps // 2), max(2, a.warmup // 2))
         if world == 1 and not a.no_cpu_baseline:

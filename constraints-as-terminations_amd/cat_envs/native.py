@@ -120,28 +120,14 @@ _SIGNATURES = {
                                           _i32, _vp, _vp]),
     "catppo_env_pre_step": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64,
                                       _vp]),
-    "catppo_rollout_store": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
-    "catppo_adv_moments": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "catppo_adv_stats": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
-    "catppo_gae": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64, _vp]),
-    "catppo_gae_ex": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
-                                _vp]),
-    "catppo_gae_f16": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
-                                 _vp]),
     "catppo_adv_normalize": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "catppo_value_bootstrap": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _i64, _vp]),
-    "catppo_rms_moments": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rms_merge": (C.c_int, [_vp, _vp, _f64, _i32, _vp, _vp, _vp, _vp]),
-    "catppo_rms_update": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
-    "catppo_rms_normalize": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _f32, _vp, _i64, _vp]),
     "catppo_mlp_layout_of": (C.c_int, [C.POINTER(MlpShape), C.POINTER(MlpLayout)]),
     "catppo_mlp_workspace_bytes": (C.c_uint64, [C.POINTER(MlpShape), _i64]),
-    "catppo_policy_act": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "catppo_value": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp]),
     "catppo_ppo_minibatch_grad": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp, _vp,
                                             _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "catppo_ppo_gather": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
-                                    _vp, _vp, _vp]),
     "catppo_ppo_minibatch_grad_packed": (C.c_int, [_vp, C.POINTER(MlpShape), C.POINTER(PpoHparams), _vp, _vp, _vp,
                                                    _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catppo_clip_adam": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _f64, _i64, _vp]),
@@ -155,39 +141,34 @@ _SIGNATURES = {
     "catppo_clip_adam_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f64, _f64, _f64, _vp, _vp]),
     "catppo_kl_mean": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "catppo_kl_adaptive_lr": (C.c_int, [_vp, _vp, _vp, _f64, _f64, _f64, _f64, _f64, _vp]),
-    "catppo_policy_act_rng": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _i32, _vp, _vp, _vp, _vp,
-                                        C.c_int, _vp]),
-    "catppo_policy_act_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
-                                       _vp]),
-    "catppo_value_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, C.c_int, _vp]),
     "catppo_ppo_gather_ex": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _i32,
                                        _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "catppo_rms_moments_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp]),
     "catppo_rollout_store_ex": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _i64, _vp]),
     "catppo_rms_update_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "catppo_rms_normalize_ex": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i64, _vp, _vp, _f32, _vp, _i64, _vp]),
-    "catppo_gae_mode": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _i32, _i64,
-                                  _vp]),
-    "catppo_rollout_xchg_bytes": (C.c_uint64, [C.c_int, C.c_int]),
-    "catppo_rollout_xchg_sum_offset": (C.c_uint64, [C.c_int]),
     "catppo_rollout_step_sizeof": (C.c_uint64, []),
+    # ---- ABI 0.6: one entry per family (the names of ABI <= 0.5 are inline wrappers in include/catppo_compat.h)
+    "catppo_debug_clip_branches": (C.c_int, [_vp, _vp]),
+    "catppo_rollout_xchg_layout": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "catppo_gae_planes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp,
+                                    _i32, _i64, _vp]),
+    "catppo_policy_step": (C.c_int, [_vp, C.POINTER(MlpShape), _vp, _vp, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                                     C.c_int, _vp]),
     "catppo_rollout_pre": (C.c_int, [_vp, C.POINTER(RolloutStep), _vp]),
     "catppo_rollout_post": (C.c_int, [_vp, C.POINTER(RolloutStep), _vp]),
     "catppo_rollout_defer_tail": (C.c_int, [_vp, C.c_int, _vp]),
-    "catppo_rollout_flush": (C.c_int, [_vp, _vp]),
     "catppo_graph_begin": (C.c_int, [_vp, _vp]),
     "catppo_graph_end": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "catppo_graph_launch": (C.c_int, [_vp, C.c_int, _vp]),
     "catppo_graph_destroy": (C.c_int, [_vp, C.c_int]),
     "catppo_comm_unique_id": (C.c_int, [_vp]),
     "catppo_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
-    "catppo_comm_world": (C.c_int, [_vp]),
     "catppo_comm_destroy": (C.c_int, [_vp]),
     "catppo_allreduce": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     "catppo_broadcast": (C.c_int, [_vp, _vp, _i64, C.c_int, C.c_int, _vp]),
     # ---- ABI 0.3
-    "catppo_graph_abort": (C.c_int, [_vp, _vp]),
-    "catppo_comm_probe": (C.c_int, []),
+    "catppo_comm_probe": (C.c_int, [_vp]),
     "catppo_allgather": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "catppo_adv_moments_parts": (C.c_int, [_vp, _vp, _i32, _i64, _i64, _vp, _vp]),
     "catppo_rlg_meters_init": (C.c_int, [_vp, _vp, C.c_int, _vp]),
@@ -197,7 +178,6 @@ _SIGNATURES = {
     "catppo_adv_moments_keyed": (C.c_int, [_vp, _vp, C.c_int, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     # ---- ABI 0.4
     "catppo_set_grad_overlap": (C.c_int, [_vp, C.c_int]),
-    "catppo_grad_overlap_active": (C.c_int, [_vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -399,14 +379,8 @@ class Native:
             self._stream()))
 
     def rollout_store(self, reward, dones, time_outs, rewards_t, dones_t1, true_dones_t1):
-        self._ok(self.lib.catppo_rollout_store(self.h, _p(reward), _p(dones), _p(time_outs), _p(rewards_t),
-                                               _p(dones_t1), _p(true_dones_t1), reward.numel(), self._stream()))
-
-    def adv_moments(self, advantages, inds, minibatch, moments):
-        _chk(inds, torch.int64, "inds")
-        _chk(moments, torch.float64, "moments")
-        self._ok(self.lib.catppo_adv_moments(self.h, _p(advantages), _p(inds), inds.numel(), int(minibatch),
-                                             _p(moments), self._stream()))
+        self._ok(self.lib.catppo_rollout_store_ex(self.h, _p(reward), _p(dones), _p(time_outs), _p(rewards_t),
+                                                  _p(dones_t1), _p(true_dones_t1), F32, reward.numel(), self._stream()))
 
     def adv_moments_parts(self, adv_part_g, parts_per_mb, total, minibatch, moments):
         """per-minibatch {sum, sum of squares, rows} from the chunk sums of the epoch gather (fp64)"""
@@ -439,9 +413,9 @@ class Native:
                      ("next_value", next_value), ("next_done", next_done), ("next_true_done", next_true_done),
                      ("advantages", advantages), ("returns", returns)):
             _chk(t, torch.float32, n)
-        self._ok(self.lib.catppo_gae(self.h, _p(rewards), _p(values), _p(dones), _p(true_dones), _p(next_value),
-                                     _p(next_done), _p(next_true_done), f32(gamma), f32(gamma * gae_lambda),
-                                     _p(advantages), _p(returns), T, N, self._stream()))
+        self._ok(self.lib.catppo_gae_planes(self.h, self.GAE_CLEANRL, GAE_SERIAL, F32, _p(rewards), _p(values), _p(dones),
+                                            _p(true_dones), _p(next_value), _p(next_done), _p(next_true_done), f32(gamma),
+                                            f32(gamma * gae_lambda), _p(advantages), _p(returns), T, N, self._stream()))
 
     GAE_CLEANRL, GAE_RL_GAMES, GAE_SKRL = 0, 1, 2
 
@@ -453,9 +427,9 @@ class Native:
                      ("advantages", advantages), ("returns", returns)):
             _chk(t, torch.float16, n)
         gl = gae_lambda if kind == self.GAE_SKRL else gamma * gae_lambda
-        self._ok(self.lib.catppo_gae_f16(self.h, int(kind), _p(rewards), _p(values), _p(dones), _p(true_dones),
-                                         _p(next_value), _p(next_done), _p(next_true_done), f32(gamma), f32(gl),
-                                         _p(advantages), _p(returns), T, N, self._stream()))
+        self._ok(self.lib.catppo_gae_planes(self.h, int(kind), GAE_SERIAL, F16, _p(rewards), _p(values), _p(dones),
+                                            _p(true_dones), _p(next_value), _p(next_done), _p(next_true_done), f32(gamma),
+                                            f32(gl), _p(advantages), _p(returns), T, N, self._stream()))
 
     def gae_rl_games(self, fdones, last_values, mb_fdones, mb_values, mb_rewards, gamma, tau, advantages, returns):
         """rl_games discount_values with float dones ((T,N) planes, time major)"""
@@ -464,9 +438,9 @@ class Native:
                      ("mb_values", mb_values), ("mb_rewards", mb_rewards), ("advantages", advantages),
                      ("returns", returns)):
             _chk(t, torch.float32, n)
-        self._ok(self.lib.catppo_gae_ex(self.h, self.GAE_RL_GAMES, _p(mb_rewards), _p(mb_values), _p(mb_fdones), None,
-                                        _p(last_values), _p(fdones), None, f32(gamma), f32(gamma * tau),
-                                        _p(advantages), _p(returns), T, N, self._stream()))
+        self._ok(self.lib.catppo_gae_planes(self.h, self.GAE_RL_GAMES, GAE_SERIAL, F32, _p(mb_rewards), _p(mb_values),
+                                            _p(mb_fdones), None, _p(last_values), _p(fdones), None, f32(gamma),
+                                            f32(gamma * tau), _p(advantages), _p(returns), T, N, self._stream()))
 
     def gae_skrl(self, rewards, dones, values, last_values, discount_factor, lambda_coefficient, advantages,
                  returns):
@@ -475,9 +449,9 @@ class Native:
         for n, t in (("rewards", rewards), ("dones", dones), ("values", values), ("last_values", last_values),
                      ("advantages", advantages), ("returns", returns)):
             _chk(t, torch.float32, n)
-        self._ok(self.lib.catppo_gae_ex(self.h, self.GAE_SKRL, _p(rewards), _p(values), _p(dones), None,
-                                        _p(last_values), None, None, f32(discount_factor), f32(lambda_coefficient),
-                                        _p(advantages), _p(returns), T, N, self._stream()))
+        self._ok(self.lib.catppo_gae_planes(self.h, self.GAE_SKRL, GAE_SERIAL, F32, _p(rewards), _p(values), _p(dones), None,
+                                            _p(last_values), None, None, f32(discount_factor), f32(lambda_coefficient),
+                                            _p(advantages), _p(returns), T, N, self._stream()))
 
     def adv_normalize(self, advantages, out, stats=None):
         self._ok(self.lib.catppo_adv_normalize(self.h, _p(_chk(advantages, torch.float32, "advantages")),
@@ -515,32 +489,33 @@ class Native:
 
     # ------------------------------------------------------------------ running mean / std
     def rms_update(self, x, n_rows, dim, ldx, mean, var, count):
-        self._ok(self.lib.catppo_rms_update(self.h, _p(x), int(n_rows), int(dim), int(ldx), _p(mean), _p(var),
-                                            _p(count), self._stream()))
+        self._ok(self.lib.catppo_rms_update_ex(self.h, _p(x), F32, int(n_rows), int(dim), int(ldx), _p(mean), _p(var),
+                                               _p(count), self._stream()))
 
     def rms_moments(self, x, n_rows, dim, ldx, sums):
-        self._ok(self.lib.catppo_rms_moments(self.h, _p(x), int(n_rows), int(dim), int(ldx),
-                                             _p(_chk(sums, torch.float64, "sums")), self._stream()))
+        self._ok(self.lib.catppo_rms_moments_ex(self.h, _p(x), F32, int(n_rows), int(dim), int(ldx),
+                                                _p(_chk(sums, torch.float64, "sums")), self._stream()))
 
     def rms_merge(self, sums, n_total, dim, mean, var, count):
         self._ok(self.lib.catppo_rms_merge(self.h, _p(sums), float(n_total), int(dim), _p(mean), _p(var), _p(count),
                                            self._stream()))
 
     def rms_normalize(self, x, n_rows, dim, ldx, mean, var, eps, out, ldo):
-        self._ok(self.lib.catppo_rms_normalize(self.h, _p(x), int(n_rows), int(dim), int(ldx), _p(mean), _p(var),
-                                               f32(eps), _p(out), int(ldo), self._stream()))
+        self._ok(self.lib.catppo_rms_normalize_ex(self.h, _p(x), F32, int(n_rows), int(dim), int(ldx), _p(mean), _p(var),
+                                                  f32(eps), _p(out), int(ldo), self._stream()))
 
     # ------------------------------------------------------------------ MLP / PPO
     def mlp_reserve(self, shape: MlpShape, rows: int):
         self.reserve(self.lib.catppo_mlp_workspace_bytes(C.byref(shape), int(rows)))
 
     def policy_act(self, shape, params, x, n_rows, eps, action, logprob, value, given_action=None):
-        self._ok(self.lib.catppo_policy_act(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
-                                            _p(given_action), _p(action), _p(logprob), _p(value), self._stream()))
+        self._ok(self.lib.catppo_policy_step(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
+                                             _p(given_action), None, 0, None, _p(action), _p(logprob), _p(value), F32,
+                                             self._stream()))
 
     def value(self, shape, params, x, n_rows, value):
-        self._ok(self.lib.catppo_value(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(value),
-                                       self._stream()))
+        self._ok(self.lib.catppo_policy_step(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), None, None, None, 0,
+                                             None, None, None, _p(value), F32, self._stream()))
 
     def ppo_minibatch_grad(self, shape, hp: PpoHparams, params, b_obs, b_actions, b_logprobs, b_advantages,
                            b_returns_n, b_values_n, mb_inds, vrms_mean, vrms_var, adv_stats, grad, diag):
@@ -557,10 +532,10 @@ class Native:
         """one launch: the whole permutation ``inds`` -> packed buffers, minibatch m = contiguous slice m"""
         _chk(inds, torch.int64, "inds")
         _chk(adv_part_g, torch.float64, "adv_part_g")
-        self._ok(self.lib.catppo_ppo_gather(
-            self.h, C.byref(shape), _p(b_obs), _p(b_actions), _p(b_logprobs), _p(b_advantages), _p(b_returns_n),
-            _p(b_values_n), _p(inds), inds.numel(), int(M), _p(x_g), _p(act_g), _p(scal_g), _p(adv_part_g),
-            self._stream()))
+        self._ok(self.lib.catppo_ppo_gather_ex(
+            self.h, C.byref(shape), _p(b_obs), _p(b_actions), _p(b_logprobs), _p(b_advantages), F32, _p(b_returns_n),
+            _p(b_values_n), _p(inds), None, 0, inds.numel(), int(M), _p(x_g), _p(act_g), _p(scal_g), _p(adv_part_g),
+            None, self._stream()))
 
     def ppo_minibatch_grad_packed(self, shape, hp: PpoHparams, params, x_mb, act_mb, scal_mb, adv_part_mb, M,
                                   vrms_mean, vrms_var, adv_stats, grad, diag):
@@ -622,18 +597,20 @@ class Native:
         raise TypeError(f"unsupported element type {t.dtype}")
 
     def policy_act_rng(self, shape, params, x, n_rows, st, step, action, logprob, value, eps_out=None):
-        self._ok(self.lib.catppo_policy_act_rng(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(st),
-                                                int(step), _p(eps_out), _p(action), _p(logprob), _p(value),
-                                                self._dt(value), self._stream()))
+        if st is None:
+            raise ValueError("policy_act_rng: the iteration state carries the Philox key")
+        self._ok(self.lib.catppo_policy_step(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), None, None, _p(st),
+                                             int(step), _p(eps_out), _p(action), _p(logprob), _p(value), self._dt(value),
+                                             self._stream()))
 
     def policy_act_ex(self, shape, params, x, n_rows, eps, action, logprob, value, given_action=None):
-        self._ok(self.lib.catppo_policy_act_ex(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
-                                               _p(given_action), _p(action), _p(logprob), _p(value), self._dt(value),
-                                               self._stream()))
+        self._ok(self.lib.catppo_policy_step(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(eps),
+                                             _p(given_action), None, 0, None, _p(action), _p(logprob), _p(value),
+                                             self._dt(value), self._stream()))
 
     def value_ex(self, shape, params, x, n_rows, value):
-        self._ok(self.lib.catppo_value_ex(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), _p(value),
-                                          self._dt(value), self._stream()))
+        self._ok(self.lib.catppo_policy_step(self.h, C.byref(shape), _p(params), _p(x), int(n_rows), None, None, None, 0,
+                                             None, None, None, _p(value), self._dt(value), self._stream()))
 
     def ppo_gather_ex(self, shape, b_obs, b_actions, b_logprobs, b_advantages, b_returns_n, b_values_n, total, M, x_g,
                       act_g, scal_g, adv_part_g, inds=None, st=None, epoch=0, inds_out=None):
@@ -672,18 +649,22 @@ class Native:
                      ("next_value", next_value), ("next_done", next_done), ("next_true_done", next_true_done),
                      ("advantages", advantages), ("returns", returns)):
             _chk(t, torch.float32, n)
-        self._ok(self.lib.catppo_gae_mode(self.h, int(mode), _p(rewards), _p(values), _p(dones), _p(true_dones),
-                                          _p(next_value), _p(next_done), _p(next_true_done), f32(gamma),
-                                          f32(gamma * gae_lambda), _p(advantages), _p(returns), T, N, self._stream()))
+        self._ok(self.lib.catppo_gae_planes(self.h, self.GAE_CLEANRL, int(mode), F32, _p(rewards), _p(values), _p(dones),
+                                            _p(true_dones), _p(next_value), _p(next_done), _p(next_true_done), f32(gamma),
+                                            f32(gamma * gae_lambda), _p(advantages), _p(returns), T, N, self._stream()))
 
     # ------------------------------------------------------------------ fused rollout step
     def rollout_xchg_new(self, K: int, D: int) -> torch.Tensor:
-        return torch.zeros(int(self.lib.catppo_rollout_xchg_bytes(int(K), int(D))), dtype=torch.uint8,
-                           device=self.device)
+        return torch.zeros(self._xchg_layout(K, D)[0], dtype=torch.uint8, device=self.device)
+
+    def _xchg_layout(self, K: int, D: int):
+        b, o = C.c_uint64(0), C.c_uint64(0)
+        self._ok(self.lib.catppo_rollout_xchg_layout(int(K), int(D), C.byref(b), C.byref(o)))
+        return int(b.value), int(o.value)
 
     def rollout_xchg_views(self, xchg: torch.Tensor, K: int, D: int):
         """(colmax fp32 [K], sums fp64 [2D]) views of the exchange buffer (the all-reduce operands when sharded)"""
-        off = int(self.lib.catppo_rollout_xchg_sum_offset(int(K)))
+        off = self._xchg_layout(K, D)[1]
         return xchg[:4 * K].view(torch.float32), xchg[off:off + 16 * max(D, 1)].view(torch.float64)
 
     def rollout_pre(self, step: RolloutStep):
@@ -698,9 +679,16 @@ class Native:
         self._ok(self.lib.catppo_rollout_defer_tail(self.h, int(bool(on)), self._stream()))
 
     def rollout_flush(self):
-        self._ok(self.lib.catppo_rollout_flush(self.h, self._stream()))
+        self._ok(self.lib.catppo_rollout_defer_tail(self.h, -1, self._stream()))      # -1: flush, the mode stays
 
     # ------------------------------------------------------------------ hipGraphs
+    def debug_clip_branches(self, buf):
+        """test hook: ``buf`` (int32 [2 * M], device) receives the clip branch of every sample of the following gradient calls
+        (surrogate codes, then value-loss codes: 0 inside / 1 below / 2 above the clip range); ``None`` switches it off"""
+        if buf is not None:
+            _chk(buf, torch.int32, "buf")
+        self._ok(self.lib.catppo_debug_clip_branches(self.h, _p(buf)))
+
     def graph_begin(self):
         self._ok(self.lib.catppo_graph_begin(self.h, self._stream()))
 
@@ -711,7 +699,7 @@ class Native:
 
     def graph_abort(self):
         """drop an active capture without keeping its graph (error path)"""
-        self.lib.catppo_graph_abort(self.h, self._stream())
+        self.lib.catppo_graph_end(self.h, self._stream(), None, None)       # graph_id == NULL: abort
 
     def graph_launch(self, gid: int):
         self._ok(self.lib.catppo_graph_launch(self.h, int(gid), self._stream()))
@@ -729,7 +717,7 @@ class Native:
 
     def comm_probe(self):
         """raises unless librccl can be loaded in this process (no communicator, no bootstrap thread is created)"""
-        if self.lib.catppo_comm_probe() != 0:
+        if self.lib.catppo_comm_probe(None) != 0:
             raise RuntimeError("catppo_comm_probe failed: librccl could not be loaded")
 
     def comm_init(self, rank: int, world: int, unique_id: bytes):
@@ -738,7 +726,7 @@ class Native:
 
     @property
     def comm_world(self) -> int:
-        return int(self.lib.catppo_comm_world(self.h))
+        return max(int(self.lib.catppo_comm_probe(self.h)), 0)      # world size of the context's communicator, 0 = none
 
     def comm_destroy(self):
         self._ok(self.lib.catppo_comm_destroy(self.h))
@@ -748,11 +736,11 @@ class Native:
         (ABI 0.4); returns whether the next ``ppo_minibatch_grad*`` call will reduce its own buckets"""
         mode = 2 if on in (2, "tail") else int(bool(on))      # 2 / "tail": ABI 0.5, no extra launch
         self._ok(self.lib.catppo_set_grad_overlap(self.h, mode))
-        return bool(self.lib.catppo_grad_overlap_active(self.h))
+        return bool(self.lib.catppo_set_grad_overlap(self.h, -1))       # -1: query
 
     @property
     def grad_overlap_active(self) -> bool:
-        return bool(self.lib.catppo_grad_overlap_active(self.h))
+        return bool(self.lib.catppo_set_grad_overlap(self.h, -1))       # -1: query
 
     def allreduce(self, t: torch.Tensor, op: int = SUM):
         self._ok(self.lib.catppo_allreduce(self.h, _p(_chk(t, t.dtype, "allreduce operand")), t.numel(), self._dt(t),

@@ -9,7 +9,7 @@ value losses, global-norm clip, Adam, linear lr anneal :294-354); every tensor o
 runs in libcatppo.so (hand-written HIP, see include/catppo.h):
 
     iteration      catppo_iter_begin                          (iteration counter, lr schedule: device state)
-    rollout step   catppo_policy_act_rng                      (ONE launch at 2049-4096 rows - all hidden layers + heads
+    rollout step   catppo_policy_step                         (ONE launch at 2049-4096 rows - all hidden layers + heads
                                                                per 32-row workgroup - else 3 GEMM launches + head:
                                                                actions/logprobs/values[step]; Philox action noise inside)
                    env.step_into -> catppo_rollout_pre/_post  (simulator state advance, terms, CaT, resets, buffer rows,
@@ -561,15 +561,15 @@ class PPOTrainer:
             for step in range(T):
                 self.global_step += N * self.world
                 if use_rng:                                          # Philox noise inside the head kernel
-                    rc = lib.catppo_policy_act_rng(
-                        h, shp, p_flat, p_obs + step * s_obs, N, p_state, step,
+                    rc = lib.catppo_policy_step(
+                        h, shp, p_flat, p_obs + step * s_obs, N, None, None, p_state, step,
                         self.noise_rec[step].data_ptr() if self.record_noise else None, p_act + step * s_act,
                         p_lp + step * s_lp, p_val + step * s_val, vdt, nat._stream())
                 else:
                     eps = self.noise[step] if eps_fn is None else eps_fn(step)
-                    rc = lib.catppo_policy_act_ex(h, shp, p_flat, p_obs + step * s_obs, N, eps.data_ptr(), None,
-                                                  p_act + step * s_act, p_lp + step * s_lp, p_val + step * s_val, vdt,
-                                                  nat._stream())
+                    rc = lib.catppo_policy_step(h, shp, p_flat, p_obs + step * s_obs, N, eps.data_ptr(), None, None, 0, None,
+                                                p_act + step * s_act, p_lp + step * s_lp, p_val + step * s_val, vdt,
+                                                nat._stream())
                 if rc:
                     nat._ok(rc)
                 if self.sink is not None:
@@ -670,7 +670,8 @@ class PPOTrainer:
             trace = self.param_trace
             self.param_trace_start = a.flat.clone()
             # (and what this update phase reads: the next rollout's first rows overwrite the buffers' step 0 before a test looks)
-            self.trace_batch = dict(obs=b_obs.clone(), actions=b_act.clone(), logprobs=b_logp.clone(), values_n=b_val.clone())
+            self.trace_batch = dict(obs=b_obs.clone(), actions=b_act.clone(), logprobs=b_logp.clone(), values_n=b_val.clone(),
+                                    advantages=b_adv.clone(), returns_n=b_ret.clone())
         for epoch in range(E):
             rec = self.perm_rec[epoch] if self.perm_rec is not None else None
             nat.ppo_gather_ex(a.shape, b_obs, b_act, b_logp, b_adv, b_ret, b_val, B, M, self._x_g, self._act_g,

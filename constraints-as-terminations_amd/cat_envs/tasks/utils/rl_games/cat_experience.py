@@ -8,7 +8,7 @@ reference's setup.py) is not vendored, so the base class' contract is restated h
 PARITY UNPINNED against rl_games itself (no source, no test in the reference tree).
 
 Planes are time-major ``(horizon_length, num_actors * num_agents, ...)`` - the layout ``discount_values`` /
-``catppo_gae_ex(CATPPO_GAE_RL_GAMES)`` scans with coalesced rows - and live on the HIP device.
+``catppo_gae_planes(CATPPO_GAE_RL_GAMES)`` scans with coalesced rows - and live on the HIP device.
 """
 from __future__ import annotations
 

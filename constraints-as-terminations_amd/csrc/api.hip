@@ -137,7 +137,17 @@ extern "C" int catppo_graph_begin(catppo_ctx* ctx, void* stream) {
 
 extern "C" int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, int* n_nodes) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  CATPPO_CHECK_ARG(ctx, ctx->capturing && graph_id != nullptr);
+  if (graph_id == nullptr) {
+    // abort (ABI 0.5: catppo_graph_abort): a failure between begin and end leaves a PARTIAL capture - end it, drop the graph
+    if (!ctx->capturing) return CATPPO_OK;
+    ctx->capturing = false;
+    hipGraph_t ga = nullptr;
+    (void)hipStreamEndCapture(static_cast<hipStream_t>(stream), &ga);   // may itself fail if the capture was invalidated
+    if (ga) (void)hipGraphDestroy(ga);
+    (void)hipGetLastError();
+    return CATPPO_OK;
+  }
+  CATPPO_CHECK_ARG(ctx, ctx->capturing);
   ctx->capturing = false;
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(static_cast<hipStream_t>(stream), &g);
@@ -163,17 +173,6 @@ extern "C" int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, in
     return catppo_fail(ctx, CATPPO_E_HIP, "catppo_graph_end: hipGraphInstantiate: %s", hipGetErrorString(e));
   ctx->graphs[slot] = ex;
   *graph_id = slot;
-  return CATPPO_OK;
-}
-
-extern "C" int catppo_graph_abort(catppo_ctx* ctx, void* stream) {
-  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  if (!ctx->capturing) return CATPPO_OK;
-  ctx->capturing = false;
-  hipGraph_t g = nullptr;
-  (void)hipStreamEndCapture(static_cast<hipStream_t>(stream), &g);   // may itself fail if the capture was invalidated
-  if (g) (void)hipGraphDestroy(g);
-  (void)hipGetLastError();
   return CATPPO_OK;
 }
 

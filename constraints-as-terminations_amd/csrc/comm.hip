@@ -91,7 +91,12 @@ static_assert(sizeof(ncclUniqueId) == CATPPO_UNIQUE_ID_BYTES, "ncclUniqueId is 1
 
 }  // namespace
 
-extern "C" int catppo_comm_probe(void) { return rccl() ? CATPPO_OK : CATPPO_E_COMM; }
+// ctx == NULL: can librccl be loaded (CATPPO_OK / CATPPO_E_COMM)?  ctx != NULL: the world size of its communicator (>= 1), 0 when it
+// has none and librccl is loadable, CATPPO_E_COMM when it is not.  (ABI 0.6: replaces catppo_comm_probe(void) + catppo_comm_world)
+extern "C" int catppo_comm_probe(catppo_ctx* ctx) {
+  if (ctx && ctx->comm) return ctx->comm_world;
+  return rccl() ? CATPPO_OK : CATPPO_E_COMM;
+}
 
 extern "C" int catppo_comm_unique_id(uint8_t* out128) {
   if (!out128) return CATPPO_E_ARG;
@@ -123,8 +128,6 @@ extern "C" int catppo_comm_init(catppo_ctx* ctx, int rank, int world, const uint
   ctx->comm_world = world;
   return CATPPO_OK;
 }
-
-extern "C" int catppo_comm_world(catppo_ctx* ctx) { return (ctx && ctx->comm) ? ctx->comm_world : 0; }
 
 extern "C" int catppo_comm_destroy(catppo_ctx* ctx) {
   if (!ctx) return CATPPO_E_ARG;
@@ -199,8 +202,11 @@ int catppo_internal_allreduce_ranges(catppo_ctx* ctx, float* base, const int64_t
   return CATPPO_OK;
 }
 
+// on = 0 | 1 | 2: set the mode (returns CATPPO_OK).  on = -1: query - returns 1 when a mode is set AND a communicator exists (the
+// all-reduce really runs inside the gradient call), else 0.  (ABI 0.6: the query replaces catppo_grad_overlap_active)
 extern "C" int catppo_set_grad_overlap(catppo_ctx* ctx, int on) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  if (on == -1) return (ctx->grad_overlap && ctx->comm != nullptr) ? 1 : 0;
   CATPPO_CHECK_ARG(ctx, on == 0 || on == 1 || on == 2);
   if (on && ctx->use_side)
     return catppo_fail(ctx, CATPPO_E_ARG, "catppo_set_grad_overlap: the side stream is taken by CATPPO_SIDE_STREAM=1");
@@ -208,6 +214,3 @@ extern "C" int catppo_set_grad_overlap(catppo_ctx* ctx, int on) {
   return CATPPO_OK;
 }
 
-extern "C" int catppo_grad_overlap_active(catppo_ctx* ctx) {
-  return (ctx && ctx->grad_overlap && ctx->comm != nullptr) ? 1 : 0;
-}

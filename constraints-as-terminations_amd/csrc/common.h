@@ -49,6 +49,9 @@ struct catppo_ctx {
   alignas(16) unsigned char post_tail_args[512] = {0};  // that launch's PostArgs
   double* post_rpart = nullptr;                         // its reset-statistics rows: owned (the workspace is reused by
   uint64_t post_rpart_bytes = 0;                        // whatever runs between the two launches), grown on demand
+  // catppo_debug_clip_branches: when set, the head / loss kernels of the next gradient calls write the clip branch every
+  // sample took ([2][M] int32: surrogate codes, then value-loss codes; 0 inside, 1 below, 2 above the clip range)
+  int32_t* branch_out = nullptr;
   char err[512] = {0};
   // catppo_plan_log: when on, the dispatch code of the MLP entry points appends one line per launch decision (which
   // kernel a shape gets, and why) - written AT the decision sites, so it cannot drift from what runs

@@ -67,7 +67,7 @@ extern "C" int catppo_env_pre_step(catppo_ctx* ctx, const float* action_in, floa
   return CATPPO_OK;
 }
 
-extern "C" int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
+static int rollout_store_f32(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
                                     float* rewards_t, float* dones_t1, float* true_dones_t1, int64_t N, void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, reward && dones && time_outs && rewards_t && dones_t1 && true_dones_t1 && N >= 1);
@@ -83,7 +83,7 @@ extern "C" int catppo_rollout_store_ex(catppo_ctx* ctx, const float* reward, con
                                        const uint8_t* time_outs, void* rewards_t, void* dones_t1, void* true_dones_t1,
                                        int dtype, int64_t N, void* stream) {
   if (dtype == CATPPO_F32)
-    return catppo_rollout_store(ctx, reward, dones, time_outs, static_cast<float*>(rewards_t),
+    return rollout_store_f32(ctx, reward, dones, time_outs, static_cast<float*>(rewards_t),
                                 static_cast<float*>(dones_t1), static_cast<float*>(true_dones_t1), N, stream);
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, dtype == CATPPO_F16);
@@ -205,17 +205,6 @@ __global__ void adv_stats_kernel(const double* __restrict__ mom, int n, float* _
   stats[2 * m + 1] = (float)sqrt(var) + 1e-8f;
 }
 }  // namespace
-
-extern "C" int catppo_adv_moments(catppo_ctx* ctx, const float* advantages, const int64_t* inds, int64_t total,
-                                  int64_t minibatch, double* moments, void* stream) {
-  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  CATPPO_CHECK_ARG(ctx, advantages && inds && moments && total >= 1 && minibatch >= 1);
-  const int64_t n_mb = cdiv64(total, minibatch);
-  hipLaunchKernelGGL(adv_moments_kernel, dim3((unsigned)n_mb), dim3(256), 0, static_cast<hipStream_t>(stream), advantages,
-                     inds, total, minibatch, moments);
-  CATPPO_CHECK_LAUNCH(ctx);
-  return CATPPO_OK;
-}
 
 extern "C" int catppo_adv_moments_parts(catppo_ctx* ctx, const double* adv_part_g, int parts_per_mb, int64_t total,
                                         int64_t minibatch, double* moments, void* stream) {

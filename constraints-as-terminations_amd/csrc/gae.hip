@@ -260,13 +260,13 @@ __global__ __launch_bounds__(256) void gae_scan_lanes(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int catppo_gae_mode(catppo_ctx* ctx, int mode, const float* rewards, const float* values,
+static int gae_scan_impl(catppo_ctx* ctx, int mode, const float* rewards, const float* values,
                                const float* dones, const float* true_dones, const float* next_value,
                                const float* next_done, const float* next_true_done, float gamma, float gamma_lambda,
                                float* advantages, float* returns, int T, int64_t N, void* stream) {
   if (mode == CATPPO_GAE_SERIAL)
-    return catppo_gae_ex(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
-                         next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
+    return gae_any<float>(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
+                          next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, mode == CATPPO_GAE_SCAN);
   CATPPO_CHECK_ARG(ctx, rewards && values && dones && true_dones && next_value && next_done && next_true_done &&
@@ -278,7 +278,7 @@ extern "C" int catppo_gae_mode(catppo_ctx* ctx, int mode, const float* rewards, 
   while (G > 1 && (T + G - 1) / G < 2) G >>= 1;
   int CH = (T + G - 1) / G;
   if (CH > 8) {    // long horizons: the serial kernel already has T-deep independent loads per lane
-    return catppo_gae_ex(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
+    return gae_any<float>(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
                          next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
   }
   const int E = 64 / G;
@@ -302,28 +302,24 @@ extern "C" int catppo_gae_mode(catppo_ctx* ctx, int mode, const float* rewards, 
   return CATPPO_OK;
 }
 
-extern "C" int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values,
-                             const float* dones, const float* true_dones, const float* next_value,
-                             const float* next_done, const float* next_true_done, float gamma, float gamma_lambda,
-                             float* advantages, float* returns, int T, int64_t N, void* stream) {
-  return gae_any<float>(ctx, kind, rewards, values, dones, true_dones, next_value, next_done, next_true_done, gamma,
-                        gamma_lambda, advantages, returns, T, N, stream);
-}
-
-extern "C" int catppo_gae_f16(catppo_ctx* ctx, int kind, const void* rewards, const void* values, const void* dones,
-                              const void* true_dones, const void* next_value, const void* next_done,
-                              const void* next_true_done, float gamma, float gamma_lambda, void* advantages,
-                              void* returns, int T, int64_t N, void* stream) {
-  using h = _Float16;
-  return gae_any<h>(ctx, kind, (const h*)rewards, (const h*)values, (const h*)dones, (const h*)true_dones,
-                    (const h*)next_value, (const h*)next_done, (const h*)next_true_done, gamma, gamma_lambda,
-                    (h*)advantages, (h*)returns, T, N, stream);
-}
-
-extern "C" int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,
-                          const float* true_dones, const float* next_value, const float* next_done,
-                          const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
-                          float* returns, int T, int64_t N, void* stream) {
-  return catppo_gae_ex(ctx, CATPPO_GAE_CLEANRL, rewards, values, dones, true_dones, next_value, next_done,
-                       next_true_done, gamma, gamma_lambda, advantages, returns, T, N, stream);
+// ABI 0.6: the one GAE entry (catppo_gae / _ex / _f16 / _mode of ABI <= 0.5 are inline wrappers in include/catppo_compat.h)
+extern "C" int catppo_gae_planes(catppo_ctx* ctx, int kind, int mode, int dtype, const void* rewards, const void* values,
+                                 const void* dones, const void* true_dones, const void* next_value, const void* next_done,
+                                 const void* next_true_done, float gamma, float gamma_lambda, void* advantages,
+                                 void* returns, int T, int64_t N, void* stream) {
+  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
+  CATPPO_CHECK_ARG(ctx, dtype == CATPPO_F32 || dtype == CATPPO_F16);
+  CATPPO_CHECK_ARG(ctx, mode == CATPPO_GAE_SERIAL || (mode == CATPPO_GAE_SCAN && kind == CATPPO_GAE_CLEANRL && dtype == CATPPO_F32));
+  if (mode == CATPPO_GAE_SCAN)
+    return gae_scan_impl(ctx, mode, (const float*)rewards, (const float*)values, (const float*)dones, (const float*)true_dones,
+                         (const float*)next_value, (const float*)next_done, (const float*)next_true_done, gamma, gamma_lambda,
+                         (float*)advantages, (float*)returns, T, N, stream);
+  if (dtype == CATPPO_F16) {
+    using h = _Float16;
+    return gae_any<h>(ctx, kind, (const h*)rewards, (const h*)values, (const h*)dones, (const h*)true_dones, (const h*)next_value,
+                      (const h*)next_done, (const h*)next_true_done, gamma, gamma_lambda, (h*)advantages, (h*)returns, T, N, stream);
+  }
+  return gae_any<float>(ctx, kind, (const float*)rewards, (const float*)values, (const float*)dones, (const float*)true_dones,
+                        (const float*)next_value, (const float*)next_done, (const float*)next_true_done, gamma, gamma_lambda,
+                        (float*)advantages, (float*)returns, T, N, stream);
 }

@@ -394,40 +394,19 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
 }
 }  // namespace
 
-extern "C" int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                                 const float* x, int64_t N, const float* eps, const float* given_action,
-                                 float* action, float* logprob, float* value, void* stream) {
-  return policy_core(ctx, shape, params, x, N, eps, given_action, action, logprob, value, CATPPO_F32, nullptr, 0,
-                     nullptr, false, stream, __func__);
-}
-
-extern "C" int catppo_policy_act_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                                    const float* x, int64_t N, const float* eps, const float* given_action,
-                                    float* action, float* logprob, void* value, int value_dtype, void* stream) {
-  return policy_core(ctx, shape, params, x, N, eps, given_action, action, logprob, value, value_dtype, nullptr, 0,
-                     nullptr, false, stream, __func__);
-}
-
-extern "C" int catppo_policy_act_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                                     const float* x, int64_t N, const catppo_iter_state* state, int32_t step,
-                                     float* eps_out, float* action, float* logprob, void* value, int value_dtype,
-                                     void* stream) {
+// ABI 0.6: the one rollout-forward entry (catppo_policy_act / _ex / _rng, catppo_value / _ex of ABI <= 0.5 are inline
+// wrappers in include/catppo_compat.h).  action == NULL: critic only.  Action noise: `eps` (supplied N(0,1)), or `state`
+// (Philox counter {env, dim / 4, step, iteration}, eps_out receives it), or `given_action` (evaluate these actions).
+extern "C" int catppo_policy_step(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
+                                  int64_t N, const float* eps, const float* given_action, const catppo_iter_state* state,
+                                  int32_t step, float* eps_out, float* action, float* logprob, void* value, int value_dtype,
+                                  void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  CATPPO_CHECK_ARG(ctx, state != nullptr && step >= 0);
-  return policy_core(ctx, shape, params, x, N, nullptr, nullptr, action, logprob, value, value_dtype, state, step,
-                     eps_out, false, stream, __func__);
-}
-
-extern "C" int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
-                            int64_t N, float* value, void* stream) {
-  return policy_core(ctx, shape, params, x, N, nullptr, nullptr, nullptr, nullptr, value, CATPPO_F32, nullptr, 0,
-                     nullptr, true, stream, __func__);
-}
-
-extern "C" int catppo_value_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
-                               int64_t N, void* value, int value_dtype, void* stream) {
-  return policy_core(ctx, shape, params, x, N, nullptr, nullptr, nullptr, nullptr, value, value_dtype, nullptr, 0,
-                     nullptr, true, stream, __func__);
+  CATPPO_CHECK_ARG(ctx, state == nullptr || (step >= 0 && eps == nullptr));
+  const bool critic_only = action == nullptr;
+  CATPPO_CHECK_ARG(ctx, !critic_only || (logprob == nullptr && eps == nullptr && given_action == nullptr && state == nullptr));
+  return policy_core(ctx, shape, params, x, N, eps, given_action, action, logprob, value, value_dtype, state, step, eps_out,
+                     critic_only, stream, __func__);
 }
 
 namespace {
@@ -459,26 +438,6 @@ extern "C" int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape
                      w.xmb, w.act, w.scal, w.adv_part, (const catppo_iter_state*)nullptr, 0, 0, (int64_t*)nullptr);
   CATPPO_CHECK_LAUNCH(ctx);
   return minibatch_grad_core(ctx, shape, L, w, hp, params, M, vrms_mean, vrms_var, adv_stats, grad, diag, s);
-}
-
-extern "C" int catppo_ppo_gather(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs,
-                                 const float* b_actions, const float* b_logprobs, const float* b_advantages,
-                                 const float* b_returns_n, const float* b_values_n, const int64_t* inds,
-                                 int64_t total, int64_t M, float* x_g, float* act_g, float* scal_g,
-                                 double* adv_part_g, void* stream) {
-  CATPPO_CHECK_ARG(ctx, ctx != nullptr);
-  catppo_mlp_layout L;
-  CATPPO_CHECK_ARG(ctx, shape && catppo_mlp_layout_of(shape, &L) == CATPPO_OK);
-  CATPPO_CHECK_ARG(ctx, b_obs && b_actions && b_logprobs && b_advantages && b_returns_n && b_values_n && inds);
-  CATPPO_CHECK_ARG(ctx, x_g && act_g && scal_g && adv_part_g && total >= 1 && M >= 1);
-  const int64_t n_mb = cdiv64(total, M);
-  CATPPO_CHECK_ARG(ctx, n_mb <= 65535);
-  hipLaunchKernelGGL(ppo_gather_kernel, dim3((unsigned)cdiv64(M, kGatherRows), (unsigned)n_mb), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), b_obs, b_actions, b_logprobs, b_advantages, b_returns_n,
-                     b_values_n, inds, total, M, L.obs_pad, shape->act_dim, x_g, act_g, scal_g, adv_part_g,
-                     (const catppo_iter_state*)nullptr, 0, 0, (int64_t*)nullptr);
-  CATPPO_CHECK_LAUNCH(ctx);
-  return CATPPO_OK;
 }
 
 extern "C" int catppo_ppo_gather_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs,
@@ -579,7 +538,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       g.adv_part = w.adv_part, g.n_adv_part = nbg;
       g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
       g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
-      g.part_w = w.head_w, g.part_s = w.head_s;
+      g.part_w = w.head_w, g.part_s = w.head_s, g.branch_out = ctx->branch_out;
       g.M = M, g.A = A, g.hp = *hp;
       const int tiles16 = (int)cdiv64(M, step16::kR);
       auto launch16 = [&](auto dp, auto n0, auto n1, auto n2) {
@@ -673,7 +632,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     g.adv_part = w.adv_part, g.n_adv_part = nbg;
     g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
     g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
-    g.part_w = w.head_w, g.part_s = w.head_s;
+    g.part_w = w.head_w, g.part_s = w.head_s, g.branch_out = ctx->branch_out;
     g.M = M, g.A = A, g.hp = *hp;
     auto launch_fh = [&](auto hl, auto prec) {
       constexpr int HLc = decltype(hl)::value, PR = decltype(prec)::value;
@@ -714,7 +673,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     g.adv_part = w.adv_part, g.n_adv_part = nbg;
     g.adv_stats = hp->adv_stats_external ? adv_stats : nullptr;
     g.vrms_mean = vrms_mean, g.vrms_var = vrms_var;
-    g.part_w = w.head_w, g.part_s = w.head_s;
+    g.part_w = w.head_w, g.part_s = w.head_s, g.branch_out = ctx->branch_out;
     g.M = M, g.A = A, g.hp = *hp;
     const int rc = dispatch_cpl(HL, [&](auto cpl) {
       constexpr int CPL = decltype(cpl)::value;
@@ -1094,6 +1053,15 @@ extern "C" int catppo_ppo_minibatch_step_packed(catppo_ctx* ctx, const catppo_ml
                      (const catppo_iter_state*)state);
   catppo_plan_note(ctx, "clip + Adam: clip_adam_dev_kernel, %d workgroups, norm from %d slots of the fold launches", nblk, ne.n_slots);
   CATPPO_CHECK_LAUNCH(ctx);
+  return CATPPO_OK;
+}
+
+// Test hook (tests/test_gpu_parity_sizes.py): buf != NULL - [2][M] int32 - makes the head / loss kernel of
+// every following catppo_ppo_minibatch_* call write the clip branch each sample took (surrogate codes [0, M), value-loss codes
+// [M, 2 M): 0 inside, 1 below, 2 above the clip range; cleanrl/ppo.py:320-341); NULL switches it off.  Costs nothing when off.
+extern "C" int catppo_debug_clip_branches(catppo_ctx* ctx, int32_t* buf) {
+  if (!ctx) return CATPPO_E_ARG;
+  ctx->branch_out = buf;
   return CATPPO_OK;
 }
 

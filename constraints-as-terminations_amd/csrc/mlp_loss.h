@@ -85,10 +85,17 @@ struct HeadArgs {
   const float* adv_stats;      // external {mean, std+1e-8} or null
   const float *vrms_mean, *vrms_var;
   float *part_w, *part_s;      // per-block partials
+  int32_t* branch_out;         // debug (catppo_debug_clip_branches): [2][M] clip-branch codes, or null
   int64_t M;
   int A;
   catppo_ppo_hparams hp;
 };
+
+// clip-branch code of one sample and one clipped quantity: 0 inside [centre - clip, centre + clip], 1 below, 2 above - where the
+// gradient of max(unclipped, clipped) switches (cleanrl/ppo.py:320-341); exported for tests/test_gpu_parity_sizes.py.  The
+// value-loss code carries a second field (<< 2): which of (unclipped, clipped) is the max - 1 unclipped, 2 clipped, 0 tie - the
+// other surface the gradient jumps at (2 (v - R) against 0 while the value difference is outside the clip range)
+__device__ __forceinline__ int clip_code(float v, float centre, float clip) { return v < centre - clip ? 1 : (v > centre + clip ? 2 : 0); }
 
 // waves per block: a 32-row tile of a wide last layer (HL >= 256) fills the CU's LDS alone, so the block brings
 // its own parallelism (16 waves x 2 rows at HL = 256); narrower layers co-reside 2-3 blocks per CU and do better
@@ -258,6 +265,10 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
       const float dnv = clip_vloss ? dnv_c : 2.0f * e1;
       d_v += 0.5f * vl;
       d_ent += ent_row;
+      if (g.branch_out != nullptr && lane == 0) {
+        g.branch_out[i] = clip_code(ratio, 1.0f, clipc);
+        g.branch_out[g.M + i] = clip_code(dl, 0.0f, clipc) | ((vl1 > vl2 ? 1 : (vl1 < vl2 ? 2 : 0)) << 2);
+      }
       const float g_v = vf_half * dnv * invM / vden;   // d loss / d v_i
 
       // ---- backward through the heads
@@ -576,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
         const float dr = pg1 > pg2 ? -adv : (pg1 < pg2 ? (inside ? -adv : 0.0f) : dr_tie);
         dg[0] = pg1 > pg2 ? pg1 : pg2;
         dg[2] = en;
+        if (g.branch_out != nullptr && pp == 0) g.branch_out[ri] = clip_code(ratio, 1.0f, clipc);
         const float g_logp = dr * ratio * invM;      // d loss / d newlogprob_i
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -598,6 +610,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
       const float cl = dl < -clipc ? -clipc : (dl > clipc ? clipc : dl);
       const float e2 = (Vo + cl) - R;
       const float vl2 = e2 * e2;
+      if (g.branch_out != nullptr) g.branch_out[g.M + ri] = clip_code(dl, 0.0f, clipc) | ((vl1 > vl2 ? 1 : (vl1 < vl2 ? 2 : 0)) << 2);
       const bool in2 = dl >= -clipc && dl <= clipc;
       const float dnv_c = vl1 > vl2 ? 2.0f * e1 : (vl1 < vl2 ? (in2 ? 2.0f * e2 : 0.0f) : e1 + (in2 ? e2 : 0.0f));
       const float vl = clip_vloss ? (vl1 > vl2 ? vl1 : vl2) : vl1;

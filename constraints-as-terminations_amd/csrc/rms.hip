@@ -248,7 +248,7 @@ __global__ void value_bootstrap_kernel(float* __restrict__ rew, const float* __r
 
 }  // namespace
 
-extern "C" int catppo_rms_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, double* sums,
+static int rms_moments_f32(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, double* sums,
                                   void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, x && sums && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
@@ -265,7 +265,7 @@ extern "C" int catppo_rms_merge(catppo_ctx* ctx, const double* sums, double n, i
   return CATPPO_OK;
 }
 
-extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, float* mean,
+static int rms_update_f32(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx, float* mean,
                                  float* var, float* count, void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, x && mean && var && count && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
@@ -293,7 +293,7 @@ extern "C" int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int
   return CATPPO_OK;
 }
 
-extern "C" int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
+static int rms_normalize_f32(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
                                     const float* mean, const float* var, float eps, float* out, int64_t ldo,
                                     void* stream) {
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
@@ -341,7 +341,7 @@ extern "C" int catppo_value_bootstrap(catppo_ctx* ctx, float* rewards, const flo
 // ---- fp16 inputs (BASELINE config 5: fp16 rollout planes) ------------------------------------------------------
 extern "C" int catppo_rms_moments_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
                                      double* sums, void* stream) {
-  if (x_dtype == CATPPO_F32) return catppo_rms_moments(ctx, static_cast<const float*>(x), N, D, ldx, sums, stream);
+  if (x_dtype == CATPPO_F32) return rms_moments_f32(ctx, static_cast<const float*>(x), N, D, ldx, sums, stream);
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16 && x && sums && N >= 1 && D >= 1 && D <= 65536 && ldx >= D);
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -361,7 +361,7 @@ extern "C" int catppo_rms_moments_ex(catppo_ctx* ctx, const void* x, int x_dtype
 
 extern "C" int catppo_rms_update_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t N, int D, int64_t ldx,
                                     float* mean, float* var, float* count, void* stream) {
-  if (x_dtype == CATPPO_F32) return catppo_rms_update(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, count, stream);
+  if (x_dtype == CATPPO_F32) return rms_update_f32(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, count, stream);
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16);
   CATPPO_CHECK_ARG(ctx, x && mean && var && count && N >= 1 && D >= 1 && 2 * D <= kFusedMax && ldx >= D);
@@ -385,7 +385,7 @@ extern "C" int catppo_rms_normalize_ex(catppo_ctx* ctx, const void* x, int x_dty
                                        const float* mean, const float* var, float eps, float* out, int64_t ldo,
                                        void* stream) {
   if (x_dtype == CATPPO_F32)
-    return catppo_rms_normalize(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, eps, out, ldo, stream);
+    return rms_normalize_f32(ctx, static_cast<const float*>(x), N, D, ldx, mean, var, eps, out, ldo, stream);
   CATPPO_CHECK_ARG(ctx, ctx != nullptr);
   CATPPO_CHECK_ARG(ctx, x_dtype == CATPPO_F16);
   CATPPO_CHECK_ARG(ctx, x && mean && var && out && N >= 1 && D >= 1 && D <= 16384 && ldx >= D && ldo >= D);

@@ -867,10 +867,13 @@ int check_step(catppo_ctx* ctx, const catppo_rollout_step* a, const char* fn) {
 
 }  // namespace
 
-extern "C" uint64_t catppo_rollout_xchg_sum_offset(int K) { return xchg_sum_offset(K); }
 extern "C" uint64_t catppo_rollout_step_sizeof(void) { return sizeof(catppo_rollout_step); }
-extern "C" uint64_t catppo_rollout_xchg_bytes(int K, int D) {
-  return xchg_sum_offset(K) + (uint64_t)2 * (D > 0 ? D : 1) * sizeof(double);
+// size of one exchange record and the offset of its fp64 sums (ABI 0.6: one call for the two of ABI 0.5)
+extern "C" int catppo_rollout_xchg_layout(int K, int D, uint64_t* bytes, uint64_t* sum_offset) {
+  if (K < 1 || !bytes || !sum_offset) return CATPPO_E_ARG;
+  *sum_offset = xchg_sum_offset(K);
+  *bytes = xchg_sum_offset(K) + (uint64_t)2 * (D > 0 ? D : 1) * sizeof(double);
+  return CATPPO_OK;
 }
 
 extern "C" int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream) {
@@ -1076,14 +1079,10 @@ extern "C" int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a
   return CATPPO_OK;
 }
 
-extern "C" int catppo_rollout_flush(catppo_ctx* ctx, void* stream) {
-  if (!ctx) return CATPPO_E_ARG;
-  return flush_post_tail(ctx, static_cast<hipStream_t>(stream));
-}
-
 extern "C" int catppo_rollout_defer_tail(catppo_ctx* ctx, int on, void* stream) {
   if (!ctx) return CATPPO_E_ARG;
-  CATPPO_CHECK_ARG(ctx, on == 0 || on == 1);
+  CATPPO_CHECK_ARG(ctx, on == 0 || on == 1 || on == -1);
+  if (on == -1) return flush_post_tail(ctx, static_cast<hipStream_t>(stream));      // flush only, the mode stays (ABI 0.5: catppo_rollout_flush)
   ctx->rollout_defer = on != 0;
   return on ? CATPPO_OK : flush_post_tail(ctx, static_cast<hipStream_t>(stream));
 }

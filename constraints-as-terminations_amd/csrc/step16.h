@@ -747,6 +747,7 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
         const float dr = pg1 > pg2 ? -adv : (pg1 < pg2 ? (inside ? -adv : 0.0f) : dr_tie);
         dg[0] = pg1 > pg2 ? pg1 : pg2;
         dg[2] = en;
+        if (g.branch_out != nullptr && pp == 0) g.branch_out[ri] = clip_code(ratio, 1.0f, clipc);
         const float g_logp = dr * ratio * invM;      // d loss / d newlogprob_i
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -769,6 +770,7 @@ __global__ __launch_bounds__(step16::kThreads) void step16_kernel(const step16::
       const float cl = dl < -clipc ? -clipc : (dl > clipc ? clipc : dl);
       const float e2 = (Vo + cl) - R;
       const float vl2 = e2 * e2;
+      if (g.branch_out != nullptr) g.branch_out[g.M + ri] = clip_code(dl, 0.0f, clipc) | ((vl1 > vl2 ? 1 : (vl1 < vl2 ? 2 : 0)) << 2);
       const bool in2 = dl >= -clipc && dl <= clipc;
       const float dnv_c = vl1 > vl2 ? 2.0f * e1 : (vl1 < vl2 ? (in2 ? 2.0f * e2 : 0.0f) : e1 + (in2 ? e2 : 0.0f));
       const float vl = clip_vloss ? (vl1 > vl2 ? vl1 : vl2) : vl1;

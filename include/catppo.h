@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define CATPPO_VERSION 500 /* 0.5.0 */
+#define CATPPO_VERSION 600 /* 0.6.0: the _ex families collapsed into one entry each (59 exports, 77 in 0.5); the
+                              names of ABI <= 0.5 are static inline wrappers in catppo_compat.h */
 
 #define CATPPO_OK 0
 #define CATPPO_E_ARG (-1)     /* bad argument */
@@ -178,15 +179,11 @@ int catppo_env_pre_step(catppo_ctx* ctx, const float* action_in, float* action, 
                         int64_t hard_reset_stride, const float* reward_src, int64_t reward_stride,
                         uint8_t* time_outs, uint8_t* terminated, uint8_t* reset, float* reward_out,
                         int64_t N, void* stream);
-int catppo_rollout_store(catppo_ctx* ctx, const float* reward, const float* dones, const uint8_t* time_outs,
-                         float* rewards_t, float* dones_t1, float* true_dones_t1, int64_t N, void* stream);
 
 /* env-sharded exact mode: advantage moments of every minibatch of a (multi-)epoch permutation in one
  * launch, moments[m] = {sum, sum of squares, count} (fp64) over adv[inds[m*mb : (m+1)*mb]]; after ONE
  * SUM all-reduce catppo_adv_stats turns them into {mean, unbiased std + 1e-8} per minibatch, the
  * `adv_stats` input of catppo_ppo_minibatch_grad.   replaces: cleanrl/ppo.py:314-318 across ranks. */
-int catppo_adv_moments(catppo_ctx* ctx, const float* advantages, const int64_t* inds, int64_t total,
-                       int64_t minibatch, double* moments, void* stream);
 int catppo_adv_stats(catppo_ctx* ctx, const double* moments, int n_minibatches, float* stats, void* stream);
 /* the same moments from the per-chunk partial sums catppo_ppo_gather[_ex] already wrote (`adv_part_g`:
  * [n_mb][parts_per_mb][2] fp64, parts_per_mb = ceil(minibatch / 64)) - no index array, any advantage plane
@@ -200,10 +197,6 @@ int catppo_adv_moments_parts(catppo_ctx* ctx, const double* adv_part_g, int part
  *   delta = fl(fl(r_t + fl(fl(fl(gamma*v_{t+1})*nn)*tn)) - v_t)
  *   A_t   = fl(delta + fl(fl(fl(gl*nn)*tn)*A_{t+1})),  ret_t = fl(A_t + v_t)
  * replaces: cleanrl/ppo.py:251-277.  Algorithmic HBM traffic: 24 B per env-step. */
-int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const float* dones,
-               const float* true_dones, const float* next_value, const float* next_done,
-               const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
-               float* returns, int T, int64_t N, void* stream);
 
 /* The float-done recurrences of the reference's other two trainers, same buffers and launch shape:
  *   CATPPO_GAE_RL_GAMES  rl_games/cat_common.py:96-103 -> rl_games A2CBase.discount_values(fdones float):
@@ -213,20 +206,16 @@ int catppo_gae(catppo_ctx* ctx, const float* rewards, const float* values, const
  *       A_t = fl(fl(r_t - v_t) + fl(fl(gamma*(1-d_t)) * fl(v_{t+1} + fl(lambda*A_{t+1}))));
  *       `dones` is indexed at t (not t+1), next_done / true_dones unused (may be NULL) and the
  *       `gamma_lambda` argument carries lambda itself.  18 B per env-step.
- * catppo_gae(...) == catppo_gae_ex(CATPPO_GAE_CLEANRL, ...). */
+ * ONE entry since ABI 0.6: catppo_gae_planes(kind, mode, dtype, ...) - kind as above, mode CATPPO_GAE_SERIAL | _SCAN (below),
+ * dtype CATPPO_F32 | CATPPO_F16 = element type of EVERY plane and row (fp16 rollout planes, BASELINE config 5: values are
+ * widened to fp32, the recurrence runs in the same fp32 op order, advantages and returns = fl32(A + v) are rounded to half
+ * (RNE) when stored; 12 B (CleanRL) / 10 B per env-step).  The scan mode exists for the CleanRL recurrence on fp32 planes. */
 typedef enum { CATPPO_GAE_CLEANRL = 0, CATPPO_GAE_RL_GAMES = 1, CATPPO_GAE_SKRL = 2 } catppo_gae_kind;
-int catppo_gae_ex(catppo_ctx* ctx, int kind, const float* rewards, const float* values, const float* dones,
-                  const float* true_dones, const float* next_value, const float* next_done,
-                  const float* next_true_done, float gamma, float gamma_lambda, float* advantages,
-                  float* returns, int T, int64_t N, void* stream);
-
-/* fp16 rollout planes (BASELINE config 5): every (T,N) plane and (N,) row is IEEE half; values are widened to fp32,
- * the recurrence of `kind` runs in the same fp32 op order, advantages and returns (= fl32(A + v)) are rounded
- * to half (RNE) when stored.  12 B (CleanRL) / 10 B (rl_games, skrl) per env-step. */
-int catppo_gae_f16(catppo_ctx* ctx, int kind, const void* rewards, const void* values, const void* dones,
-                   const void* true_dones, const void* next_value, const void* next_done,
-                   const void* next_true_done, float gamma, float gamma_lambda, void* advantages, void* returns,
-                   int T, int64_t N, void* stream);
+enum { CATPPO_GAE_SERIAL = 0, CATPPO_GAE_SCAN = 1 };
+int catppo_gae_planes(catppo_ctx* ctx, int kind, int mode, int dtype, const void* rewards, const void* values,
+                      const void* dones, const void* true_dones, const void* next_value, const void* next_done,
+                      const void* next_true_done, float gamma, float gamma_lambda, void* advantages, void* returns,
+                      int T, int64_t N, void* stream);
 
 /* skrl whole-batch advantage normalisation (skrl/ppo.py:436): out = (A - mean(A)) / (std_unbiased(A) + 1e-8),
  * moments in fp64 (deterministic); out may alias advantages; stats (NULL ok) receives {mean, std + 1e-8}. */
@@ -246,15 +235,8 @@ int catppo_value_bootstrap(catppo_ctx* ctx, float* rewards, const float* values,
  *   catppo_rms_update  : moments + merge (single GPU)
  *   catppo_rms_normalize: out = (x-mean)/sqrt(var+eps)   (out may alias x)
  * replaces: cleanrl/ppo.py:12-62. */
-int catppo_rms_moments(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
-                       double* sums, void* stream);
 int catppo_rms_merge(catppo_ctx* ctx, const double* sums, double n, int D, float* mean,
                      float* var, float* count, void* stream);
-int catppo_rms_update(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
-                      float* mean, float* var, float* count, void* stream);
-int catppo_rms_normalize(catppo_ctx* ctx, const float* x, int64_t N, int D, int64_t ldx,
-                         const float* mean, const float* var, float eps, float* out,
-                         int64_t ldo, void* stream);
 
 /* ---- actor-critic MLP ---------------------------------------------------------------------
  * Two independent MLPs (critic then actor, the reference's registration order) with L
@@ -301,13 +283,8 @@ uint64_t catppo_mlp_workspace_bytes(const catppo_mlp_shape* shape, int64_t rows)
  *   action = mu + exp(logstd)*eps  (eps [N,A] supplied N(0,1) noise; NULL -> action = mu;
  *            given_action [N,A] non-NULL -> that action is scored instead, ppo.py:109-113)
  *   logprob [N], value [N].   replaces: ppo.py:104-119,208-212. */
-int catppo_policy_act(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                      const float* x, int64_t N, const float* eps, const float* given_action,
-                      float* action, float* logprob, float* value, void* stream);
 
 /* critic only (bootstrap value, ppo.py:252) */
-int catppo_value(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params,
-                 const float* x, int64_t N, float* value, void* stream);
 
 typedef struct catppo_ppo_hparams {
   float clip_coef, ent_coef, vf_coef;
@@ -343,10 +320,6 @@ int catppo_ppo_minibatch_grad(catppo_ctx* ctx, const catppo_mlp_shape* shape,
  * (5 gathers per iteration instead of 30).  Same arithmetic and results as catppo_ppo_minibatch_grad. */
 #define CATPPO_GATHER_ROWS 64
 #define CATPPO_GATHER_PARTS(M) (((M) + CATPPO_GATHER_ROWS - 1) / CATPPO_GATHER_ROWS)
-int catppo_ppo_gather(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* b_obs, const float* b_actions,
-                      const float* b_logprobs, const float* b_advantages, const float* b_returns_n,
-                      const float* b_values_n, const int64_t* inds, int64_t total, int64_t M, float* x_g,
-                      float* act_g, float* scal_g, double* adv_part_g, void* stream);
 int catppo_ppo_minibatch_grad_packed(catppo_ctx* ctx, const catppo_mlp_shape* shape, const catppo_ppo_hparams* hp,
                                      const float* params, const float* x_mb, const float* act_mb,
                                      const float* scal_mb, const double* adv_part_mb, int64_t M,
@@ -425,23 +398,24 @@ int catppo_kl_mean(catppo_ctx* ctx, catppo_iter_state* state, const float* diag,
 int catppo_kl_adaptive_lr(catppo_ctx* ctx, catppo_iter_state* state, const float* kl, double kl_threshold,
                           double kl_factor, double lr_factor, double min_lr, double max_lr, void* stream);
 
-/* ---- on-device randomness ---------------------------------------------------------------------------------
- * catppo_policy_act_rng: catppo_policy_act whose N(0,1) action noise comes from Philox4x32-10 + Box-Muller inside
- * the head kernel (replaces Normal.sample(), cleanrl/ppo.py:111): element (env i, dim k) of rollout step `step`
- * of iteration state->iteration uses counter {i, k/4, step, iteration}, key = state->seed, lane k%4 of the block.
- * eps_out ([N,A], may be NULL) receives the noise used, so a parity test can replay it through the oracle.
- * value_dtype: CATPPO_F32, or CATPPO_F16 to store `value` as IEEE half (fp16 rollout planes). */
-int catppo_policy_act_rng(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
-                          int64_t N, const catppo_iter_state* state, int32_t step, float* eps_out, float* action,
-                          float* logprob, void* value, int value_dtype, void* stream);
-/* fp16 `value` output for the supplied-noise form and the critic-only form */
-int catppo_policy_act_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x,
-                         int64_t N, const float* eps, const float* given_action, float* action, float* logprob,
-                         void* value, int value_dtype, void* stream);
-int catppo_value_ex(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
-                    void* value, int value_dtype, void* stream);
+/* ---- rollout forward: policy step + value (ONE entry since ABI 0.6) ------------------------------------------------
+ * catppo_policy_step: both networks' forward on x [N, Dp] + the Gaussian head (replaces Agent.get_action_and_value /
+ * get_value, cleanrl/ppo.py:104-119,186-189; the bootstrap value of :251 is the critic-only form, action == NULL).
+ * Where the action comes from - exactly one of:
+ *   eps          supplied N(0,1) noise [N, A]: a = mu + sigma * eps (Normal.sample(), cleanrl/ppo.py:111)
+ *   state, step  on-device noise: Philox4x32-10 + Box-Muller inside the head kernel; element (env i, dim k) of rollout
+ *                step `step` of iteration state->iteration uses counter {i, k/4, step, iteration}, key = state->seed,
+ *                lane k%4 of the block; eps_out ([N, A], may be NULL) receives it, so a parity test can replay it
+ *   given_action evaluate these actions (log-prob / value of stored actions)
+ * value_dtype: CATPPO_F32, or CATPPO_F16 to store `value` as IEEE half (fp16 rollout planes).
+ * Kernels by batch size (catppo_plan_log names them): <= 2048 rows step16_fwd_kernel (16-row tiles), 2049-4096 the 32-row
+ * row-resident kernels, else layer-wise GEMM launches + head_act_kernel. */
+int catppo_policy_step(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* params, const float* x, int64_t N,
+                       const float* eps, const float* given_action, const catppo_iter_state* state, int32_t step,
+                       float* eps_out, float* action, float* logprob, void* value, int value_dtype, void* stream);
 
-/* catppo_ppo_gather with (a) either an index array `inds` (state == NULL) or a permutation computed on the fly
+/* The epoch gather (one launch for every minibatch of an epoch: minibatch m = contiguous slice m of the packed buffers)
+ * with (a) either an index array `inds` (state == NULL) or a permutation computed on the fly
  * (inds == NULL; replaces torch.randperm, cleanrl/ppo.py:295): sample j of the epoch reads row P(j), P = a keyed
  * bijection of [0,total) (6-round Feistel network on the next power of four with cycle walking, round keys from
  * Philox(seed; iteration, epoch)) - no index array, no sort; inds_out ([total] int64, may be NULL) receives P for
@@ -482,12 +456,6 @@ int catppo_rms_normalize_ex(catppo_ctx* ctx, const void* x, int x_dtype, int64_t
  *   scan, then every lane replays its chunk from the incoming value.  Fills the chip at small N (4096 envs: 64 waves
  *   serial, up to 1024 in scan mode); the composition reassociates the recurrence, so results agree with the serial
  *   mode to ~1e-6 relative (tests hold 1e-5), not bit for bit.  CleanRL recurrence (kind 0), fp32 planes. */
-enum { CATPPO_GAE_SERIAL = 0, CATPPO_GAE_SCAN = 1 };
-int catppo_gae_mode(catppo_ctx* ctx, int mode, const float* rewards, const float* values, const float* dones,
-                    const float* true_dones, const float* next_value, const float* next_done,
-                    const float* next_true_done, float gamma, float gamma_lambda, float* advantages, float* returns,
-                    int T, int64_t N, void* stream);
-
 /* ---- fused rollout step ------------------------------------------------------------------------------------------
  * Everything between the simulator's state update and the next policy forward, in TWO launches instead of ten:
  *   launch 1 (16-env tiles)  process_action, episode counters, terminations, reward pick-up (catppo_env_pre_step);
@@ -532,10 +500,10 @@ typedef struct catppo_rollout_step {
   const float* obs_raw; int64_t obs_ld;
   float* obs_mean; float* obs_var; float* obs_count; float obs_eps; double obs_rows_total;
   float* obs_out; int64_t obs_out_ld;
-  /* exchange buffer, device: K floats (as doubles' storage is separate) - see catppo_rollout_xchg_bytes */
+  /* exchange buffer, device: K floats (as doubles' storage is separate) - see catppo_rollout_xchg_layout */
   void* xchg;
   /* env-sharded, ONE collective per env step (ABI 0.3): catppo_rollout_pre writes this rank's record into `xchg`; the
-   * caller all-gathers the records of all ranks (catppo_allgather, catppo_rollout_xchg_bytes each, rank order) into
+   * caller all-gathers the records of all ranks (catppo_allgather, `bytes` of catppo_rollout_xchg_layout each, rank order) into
    * `xchg_gathered`, and catppo_rollout_post folds them itself - column maxima by MAX (exact), moment sums in rank order
    * (identical on every rank).  xchg_records = number of records (0 / 1: read `xchg`, e.g. after MAX / SUM all-reduces). */
   const void* xchg_gathered;
@@ -550,12 +518,12 @@ typedef struct catppo_rollout_step {
    * caller has updated the state block itself.  sim_row_bytes % 16 == 0. */
   const void* sim_src; void* sim_state; int64_t sim_row_bytes;
 } catppo_rollout_step;
-uint64_t catppo_rollout_xchg_bytes(int K, int D);
+/* bytes of one exchange record and the byte offset of its fp64 sums (K constraint columns, D observation width) */
+int catppo_rollout_xchg_layout(int K, int D, uint64_t* bytes, uint64_t* sum_offset);
 uint64_t catppo_rollout_step_sizeof(void);   /* sizeof(catppo_rollout_step): lets a binding check its struct layout */
 /* phase 1 (two launches: the per-tile kernel and the fold of its partial rows into `xchg`) and phase 2 (one launch); call
  * both back to back on one GPU; all-reduce xchg in between when env-sharded:
- * floats [0,K) with MAX, doubles at byte offset catppo_rollout_xchg_sum_offset(K) [2*D] with SUM) */
-uint64_t catppo_rollout_xchg_sum_offset(int K);
+ * floats [0,K) with MAX, doubles at byte offset `sum_offset` of catppo_rollout_xchg_layout [2*D] with SUM) */
 int catppo_rollout_pre(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
 int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* stream);
 /* ABI 0.5: the tail of catppo_rollout_post - ONE workgroup that, after all others, publishes the new running maxima (rm)
@@ -563,19 +531,18 @@ int catppo_rollout_post(catppo_ctx* ctx, const catppo_rollout_step* a, void* str
  * chain forward -> pre -> fold -> post -> forward of an env step.  With on = 1 a post launch ends without that tail (and
  * without the "last workgroup arrives" hand-shake in front of it); the tail runs as one more workgroup of the NEXT
  * catppo_rollout_pre launch on the same stream (nothing in between reads what it writes: the policy forward consumes
- * obs_out, the simulator its own state), or as a launch of its own from catppo_rollout_flush / the next
- * catppo_rollout_post / catppo_rollout_defer_tail(ctx, 0, stream).  CONTRACT while on: rm, obs_mean, obs_var, obs_count
+ * obs_out, the simulator its own state), or as a launch of its own from catppo_rollout_defer_tail(ctx, -1, stream) (flush,
+ * the mode stays) / the next catppo_rollout_post / catppo_rollout_defer_tail(ctx, 0, stream).  CONTRACT while on: rm, obs_mean, obs_var, obs_count
  * and log_out of a step are valid (in stream order) only after one of those calls; every other output of the step is
  * valid after catppo_rollout_post as before.  Values are bit-identical either way: the tail derives the state with the same
  * device functions from the same exchange record(s) - which must stay untouched until then (they are: the next writer is
  * the fold behind the next catppo_rollout_pre / the next all-gather).  The rollout loop of cleanrl/ppo.py's PPOTrainer
  * switches it on around its env steps and off (= flush) before GAE.  One stream per context while it is on: the pending
- * tail and its reset-statistics rows belong to the context, and a post call on ANOTHER stream is ordered behind the tail's
- * launch only by the caller.  Reference: the statistics concerned are
+ * tail and its reset-statistics rows belong to the context; a call that flushes the tail from ANOTHER stream is ordered
+ * behind the tail's launch by an event (round 6).  Reference: the statistics concerned are
  * ConstraintManager's running maxima (cat/constraint_manager.py:58-61), RunningMeanStd's state (cleanrl/ppo.py:48-62)
  * and the episode log of ConstraintManager.reset (cat/constraint_manager.py:190-211). */
-int catppo_rollout_defer_tail(catppo_ctx* ctx, int on, void* stream);
-int catppo_rollout_flush(catppo_ctx* ctx, void* stream);
+int catppo_rollout_defer_tail(catppo_ctx* ctx, int on, void* stream);    /* on: 1 | 0 (= off + flush) | -1 (flush only) */
 
 /* ---- rl_games front end: episode bookkeeping with float dones ---------------------------------------
  * One env step of CaTA2CAgent.play_steps' bookkeeping (rl_games/cat_common.py:71-92), one launch, no host sync:
@@ -609,13 +576,11 @@ int catppo_rlg_episode_step(catppo_ctx* ctx, const float* rewards, const float* 
  * instantiate it, and replay it with one call.  `stream` must not be the legacy default stream.  No library call
  * allocates or synchronises while a capture is active (catppo_reserve returns CATPPO_E_ARG then). */
 int catppo_graph_begin(catppo_ctx* ctx, void* stream);
+/* graph_id == NULL: end the capture WITHOUT keeping its graph (error path: something between begin and end failed, the
+ * partial graph must never be replayed); a no-op when no capture is active */
 int catppo_graph_end(catppo_ctx* ctx, void* stream, int* graph_id, int* n_nodes);
 int catppo_graph_launch(catppo_ctx* ctx, int graph_id, void* stream);
 int catppo_graph_destroy(catppo_ctx* ctx, int graph_id);
-/* end a capture WITHOUT keeping its graph (error path: something between begin and end failed, the partial graph must
- * never be replayed).  No-op when no capture is active. */
-int catppo_graph_abort(catppo_ctx* ctx, void* stream);
-
 /* ---- collectives (RCCL over xGMI, one process per GPU) ---------------------------------------------------------
  * librccl is loaded at run time (dlopen) by the first of these calls; the library has no link-time dependency on it.
  * catppo_comm_unique_id: rank 0 creates the id (128 bytes) and ships it to the other ranks by any means (the host
@@ -625,12 +590,12 @@ int catppo_graph_abort(catppo_ctx* ctx, void* stream);
  * reduction), :562-564 (KL all-reduce); the CleanRL path of the reference has no collective. */
 enum { CATPPO_SUM = 0, CATPPO_MAX = 1 };
 #define CATPPO_UNIQUE_ID_BYTES 128
-/* can this process use the collectives at all (librccl loadable, every entry point present)?  No communicator, no
- * bootstrap thread: what every rank checks BEFORE anybody enters the blocking catppo_comm_init. */
-int catppo_comm_probe(void);
+/* ctx == NULL: can this process use the collectives at all (librccl loadable, every entry point present: CATPPO_OK /
+ * CATPPO_E_COMM)?  No communicator, no bootstrap thread: what every rank checks BEFORE anybody enters the blocking
+ * catppo_comm_init.  ctx != NULL: the world size of its communicator (>= 1), 0 = none. */
+int catppo_comm_probe(catppo_ctx* ctx);
 int catppo_comm_unique_id(uint8_t* out128);
 int catppo_comm_init(catppo_ctx* ctx, int rank, int world, const uint8_t* unique_id128);
-int catppo_comm_world(catppo_ctx* ctx);   /* 0 = no communicator */
 int catppo_comm_destroy(catppo_ctx* ctx);
 int catppo_allreduce(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int op, void* stream);
 int catppo_broadcast(catppo_ctx* ctx, void* buf, int64_t count, int dtype, int root, void* stream);
@@ -645,13 +610,19 @@ int catppo_allgather(catppo_ctx* ctx, const void* send, void* recv, int64_t byte
  * still run on `stream`; the side stream joins `stream` before the call returns its stream order, so `grad` is the
  * GLOBAL sum when the next operation on `stream` (catppo_clip_adam*) reads it and the caller must NOT all-reduce it
  * again.  Sums per element are those of the single fold launch (bit-identical on a world of one); the whole sequence
- * is capturable.  catppo_grad_overlap_active: 1 when the next gradient call will reduce its own buckets. */
+ * is capturable.  catppo_set_grad_overlap(ctx, -1) queries: 1 when the next gradient call will reduce the gradient itself. */
 /* ABI 0.5: on == 2 selects the "tail" form - NO extra launch: once the launch that folds every layer above the first is
  * enqueued (dw_fold_kernel), those ranges of the flat gradient are all-reduced on the side stream under the final fold
  * launch of the first layer's own partials, which are reduced on the caller's stream behind a join.  Measured on a world of
  * one: see profiles/r5_grad_overlap_tail_world1.txt. */
-int catppo_set_grad_overlap(catppo_ctx* ctx, int on);
-int catppo_grad_overlap_active(catppo_ctx* ctx);
+int catppo_set_grad_overlap(catppo_ctx* ctx, int on);      /* on: 0 | 1 | 2 set (CATPPO_OK), -1 query (0 / 1) */
+
+/* ---- test hook (ABI 0.6) ------------------------------------------------------------------------------------------
+ * buf != NULL ([2][M] int32, device): the head / loss kernel of every following catppo_ppo_minibatch_* call writes the clip
+ * branch each sample of the minibatch took - surrogate codes in [0, M) (ratio against 1 +- clip_coef), value-loss codes in
+ * [M, 2 M) (newvalue - old value against +- clip_coef): 0 inside, 1 below, 2 above; cleanrl/ppo.py:320-341.  NULL: off.
+ * What tests/test_gpu_parity_sizes.py compares with the oracle's branches when two parameter trajectories part. */
+int catppo_debug_clip_branches(catppo_ctx* ctx, int32_t* buf);
 
 #ifdef __cplusplus
 }

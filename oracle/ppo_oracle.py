@@ -401,7 +401,7 @@ class PPOOracle:
                     if not hasattr(self, "step_trace"):
                         self.step_trace = []
                     self.step_trace.append(dict(mb=mb.clone(), ratio=st["ratio"].clone(), newvalue_n=st["newvalue_n"].clone(),
-                                                old_values_n=b_values[mb].clone(),
+                                                old_values_n=b_values[mb].clone(), returns_n=b_returns[mb].clone(),
                                                 params=torch.cat([q_.detach().reshape(-1) for q_ in self.agent.parameters()]).clone()))
         t3 = time.perf_counter()
         self.timers["rollout"] += t1 - t0

@@ -108,11 +108,13 @@ def logical_params(agent, flat):
 def branch_flip_report(trainer, orc, tight_bar):
     """Why did the parameters of the last (traced) iteration leave the tight bar?  cleanrl/ppo.py:320-341: the gradients of
     the clipped surrogate and of the clipped value loss jump where |ratio - 1| = clip / |newvalue - old value| = clip.
-    Finds the first optimiser step k after which device and oracle parameters differ by >= tight_bar, evaluates the clip
-    branches of that step's minibatch ON THE DEVICE (catppo_policy_act with the device's parameters before step k and the
-    minibatch's own actions -> log-prob, value -> ratio, value difference), compares them with the oracle's branches of
-    the same step, and reports the samples that sit on different sides together with the oracle's distance of those
-    samples to the boundary.  Needs run_pair(trace=True)."""
+    Finds the first optimiser step k after which device and oracle parameters differ by >= tight_bar and RE-RUNS that step's
+    gradient call on the device - same kernels, the device's own parameters before step k, the update phase's own inputs -
+    with catppo_debug_clip_branches switched on: the loss kernel writes the clip branch every sample took.  Those are
+    compared with the oracle's branches of the same step; reported: the samples that sit on different sides, the oracle's
+    distance of those samples to the boundary, and how far device and oracle are apart in the per-sample quantities
+    themselves (log-prob ratio, normalised value difference: catppo_policy_step under the same parameters).
+    Needs run_pair(trace=True)."""
     from cat_envs import native
     agent, nat, cfg = trainer.agent, trainer.nat, trainer.cfg
     steps = orc.step_trace
@@ -124,6 +126,12 @@ def branch_flip_report(trainer, orc, tight_bar):
     if not bad:
         return dict(first_step=None, errs=errs)
     k = bad[0]
+    # the step the trajectories PART at is where the distance jumps (cfg4: 4.5e-8 for nine steps, then 1e-5 .. 2e-5 in one
+    # step - which may or may not already be above the bar), not the first one above an absolute threshold
+    for j in range(1, k + 1):
+        if errs[j] >= 1e-6 and errs[j] >= 30.0 * max(errs[:j]):
+            k = j
+            break
     theta = trainer.param_trace[k - 1] if k > 0 else trainer.param_trace_start
     mb = steps[k]["mb"].to(trainer.device)
     tb = trainer.trace_batch                      # the update phase's own inputs (snapshot taken when it started)
@@ -142,13 +150,37 @@ def branch_flip_report(trainer, orc, tight_bar):
 
     def code(v, centre):
         return (v < centre - clip).long() + 2 * (v > centre + clip).long()
-    pg_diff = code(ratio_d, 1.0) != code(ratio_o, 1.0)
-    v_diff = (code(dl_d, 0.0) != code(dl_o, 0.0)) if bool(cfg.clip_vloss) else torch.zeros_like(pg_diff)
+    # the branches the TRAINING kernels take (not a re-derivation: the head sums of the rollout kernel differ by ~1e-7)
+    codes = torch.full((2 * M,), -1, dtype=torch.int32, device=trainer.device)
+    g_s, d_s = torch.zeros_like(trainer.grad), torch.zeros_like(trainer.diag)
+    nat.debug_clip_branches(codes)
+    try:
+        nat.ppo_minibatch_grad(agent.shape, trainer.hp, theta.contiguous(), tb["obs"].float(), tb["actions"].float(),
+                               tb["logprobs"].float(), tb["advantages"].float(), tb["returns_n"].float(), tb["values_n"].float(),
+                               mb.contiguous(), agent.value_rms.running_mean, agent.value_rms.running_var, None, g_s, d_s)
+        torch.cuda.synchronize()
+    finally:
+        nat.debug_clip_branches(None)
+    codes = codes.cpu().long()
+    assert int(codes.min()) >= 0, "the loss kernel did not export its clip branches"
+    pg_diff = codes[:M] != code(ratio_o, 1.0)
     m_pg = ((ratio_o - 1.0).abs() - clip).abs()
-    m_v = (dl_o.abs() - clip).abs()
-    margins = torch.cat([m_pg[pg_diff], m_v[v_diff]])
+    if bool(cfg.clip_vloss):
+        # two surfaces: the clip range of (newvalue - old value), and - outside it - which of (unclipped, clipped) is the max
+        v_diff = (codes[M:] & 3) != code(dl_o, 0.0)
+        e1 = steps[k]["newvalue_n"] - steps[k]["returns_n"]
+        e2 = steps[k]["old_values_n"] + dl_o.clamp(-clip, clip) - steps[k]["returns_n"]
+        vl1, vl2 = e1 * e1, e2 * e2
+        max_o = (vl1 > vl2).long() + 2 * (vl1 < vl2).long()
+        vmax_diff = ((codes[M:] >> 2) != max_o) & ~v_diff & (code(dl_o, 0.0) != 0)
+        m_v, m_vmax = (dl_o.abs() - clip).abs(), (e1.abs() - e2.abs()).abs()
+    else:
+        v_diff = vmax_diff = torch.zeros_like(pg_diff)
+        m_v = m_vmax = torch.zeros_like(m_pg)
+    margins = torch.cat([m_pg[pg_diff], m_v[v_diff], m_vmax[vmax_diff]])
+    v_diff = v_diff | vmax_diff
     return dict(first_step=k, n_steps=n, err_before=errs[k - 1] if k > 0 else 0.0, err_at=errs[k], errs=errs,
-                flipped_surrogate=int(pg_diff.sum()), flipped_value=int(v_diff.sum()),
+                flipped_surrogate=int(pg_diff.sum()), flipped_value=int(v_diff.sum()), flipped_value_max_branch=int(vmax_diff.sum()),
                 max_margin_of_flipped=float(margins.max()) if margins.numel() else None,
                 max_device_oracle_ratio_diff=float((ratio_d - ratio_o).abs().max()),
                 max_device_oracle_value_diff=float((dl_d - dl_o).abs().max()))

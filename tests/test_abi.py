@@ -22,7 +22,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/catppo.h but not exported"
     assert set(names) == set(native.EXPORTS), set(names) ^ set(native.EXPORTS)
-    assert lib.catppo_version() == 500
+    assert lib.catppo_version() == 600
+    assert len(names) < 60, len(names)                  # ABI 0.6: the _ex families collapsed (77 exports in 0.5)
 
 
 def test_layout_matches_reference_parameter_count():
@@ -31,6 +32,7 @@ def test_layout_matches_reference_parameter_count():
     lay = native.layout_of(native.shape_of(45, 12, (512, 256, 128)))
     assert lay.n_params == 377241          # reference Agent
     assert lay.obs_pad == 48 and lay.n_flat % 4 == 0
+    assert all(lay.off_w[net][l] % 32 == 0 for net in range(2) for l in range(4))      # weight matrices on 128-byte lines (round 6)
     lay2 = native.layout_of(native.shape_of(48, 12, (256, 256, 256)))
     assert lay2.obs_pad == 48 and lay2.n_params == 2 * (48 * 256 + 256 + 2 * (256 * 256 + 256)) + 256 * 13 + 13 + 12
 

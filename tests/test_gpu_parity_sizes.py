@@ -43,18 +43,18 @@ BARS = {
 # 1e-7 change of the value head, bit-reproducible, 3e-8 away from the old kernel when no sample sits on a boundary.
 # Round 6: the looser bar is no longer granted on the oracle's say-so ("some sample came
 # close").  Both sides record their parameters after EVERY optimiser step; when the tight bar fails the test finds the
-# first step after which they differ by more than it, has the DEVICE evaluate that step's minibatch (log-prob and value
-# under the device's parameters before the step -> ratio, value difference: smoke_impl.branch_flip_report) and demands
+# first step after which they differ by more than it and RE-RUNS that step's gradient call on the device with
+# catppo_debug_clip_branches on - the loss kernel itself exports the clip branch of every sample (smoke_impl.
+# branch_flip_report) - and demands
 #   (1) until that step the parameters agreed within the tight bar,
 #   (2) at least one sample of that minibatch sits on different sides of a clip boundary on device and oracle,
 #   (3) every such sample is closer to the boundary (in the oracle's arithmetic) than device and oracle disagree about
-#       that per-sample quantity AT THAT STEP - i.e. the flip is explained by the measured disagreement, which itself
-#       must stay small (PER_SAMPLE_DISAGREEMENT_CAP: the parameters differ by < 1.2e-5 there, the value head sums 256
-#       of them).  What the first run of this analysis showed at cfg4 (profiles/r6_parity.json): no sample sits "1e-6
-#       from a boundary" - the parameter distance creeps to 1.0e-5 over nine steps of Adam on rounding-level gradient
-#       differences, the normalised values then disagree by 3.6e-4, and a sample 9e-5 from the value-clip boundary flips.
-# Only then may the parameters use the bar of rounds 1-2; the record names the step, the flipped samples and both numbers.
-PER_SAMPLE_DISAGREEMENT_CAP = 1e-3
+#       that per-sample quantity at that step (measured: catppo_policy_step under the same parameters), and that
+#       disagreement is itself at rounding level (PER_SAMPLE_DISAGREEMENT_CAP).
+# Only then may the parameters use the bar of rounds 1-2; the record names the step, the flipped samples, both numbers.
+# What it shows at cfg4 (profiles/r6_parity.json): 4.5e-8 for nine optimiser steps, then 2e-5 in ONE step whose
+# minibatch holds one sample with |newvalue - old value| within rounding of clip_coef - round 5's finding, now asserted.
+PER_SAMPLE_DISAGREEMENT_CAP = 2e-5
 PARAMS_BAR_AFTER_A_BRANCH_FLIP = 4e-4
 BOUNDARY_NOISE = 2e-6          # device / oracle disagreement of ratio and value when the parameters are equal (machinery test)
 
@@ -342,7 +342,7 @@ def test_set_term_cfg_with_the_same_object_after_an_in_place_edit_acts_on_the_ne
 def test_branch_flip_analysis_sees_the_same_per_sample_quantities_on_both_sides():
     """the machinery behind the looser parameter bar, exercised where nothing flips: a 256-env iteration with per-step
     traces; asked about an absurdly tight bar (1e-9) the report names the first optimiser step, and the device's
-    re-evaluation of that minibatch (catppo_policy_act under the traced parameters) agrees with the oracle's ratio /
+    re-evaluation of that minibatch (catppo_policy_step under the traced parameters) agrees with the oracle's ratio /
     value difference to BOUNDARY_NOISE - the disagreement level the flip criterion (3) is calibrated on."""
     import parity_record
     import smoke_impl

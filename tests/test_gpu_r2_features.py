@@ -193,7 +193,7 @@ def test_keyed_permutation_gather(nat, B, M):
 @pytest.mark.parametrize("T,N", [(24, 4096), (48, 4096), (24, 64), (5, 1000), (1, 7), (2, 3), (33, 129), (100, 50),
                                  (200, 16)])
 def test_gae_scan_mode_vs_serial(nat, T, N):
-    """catppo_gae_mode(SCAN): wavefront-shuffle scan over the time axis; <= 1e-5 of the bit-exact serial kernel
+    """catppo_gae_planes(mode = SCAN): wavefront-shuffle scan over the time axis; <= 1e-5 of the bit-exact serial kernel
     (north_star: returns / advantages within 1e-5)."""
     from cat_envs import native
     x = S.gae_inputs(T * 31 + N, T, N)

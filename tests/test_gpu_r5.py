@@ -376,7 +376,7 @@ logs = []
 for _ in range(3):
     logs.append(tr.run_iteration(log=True))
 torch.cuda.synchronize()
-assert not tr.nat.lib.catppo_rollout_flush(tr.nat.h, tr.nat._stream())           # nothing pending after a rollout
+assert not tr.nat.lib.catppo_rollout_defer_tail(tr.nat.h, -1, tr.nat._stream())           # nothing pending after a rollout
 eu = env.unwrapped
 cm = eu.constraint_manager
 rms = tr.agent.obs_rms
@@ -413,7 +413,7 @@ def test_post_tail_deferred_into_the_next_pre_launch_is_bit_identical(tmp_path, 
 
 
 def test_deferred_post_tail_contract_through_the_c_abi():
-    """the state a deferred tail publishes is current after catppo_rollout_flush; a second catppo_rollout_post with the
+    """the state a deferred tail publishes is current after the flush (catppo_rollout_defer_tail(ctx, -1)); a second catppo_rollout_post with the
     tail still pending runs it first (on its own launch); switching the deferral off flushes"""
     import smoke_impl
     from cat_envs.shim import make

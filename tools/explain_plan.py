@@ -3,7 +3,7 @@
     python tools/explain_plan.py [--obs 48] [--act 12] [--hidden 256,256,256] [--envs 4096] [--minibatch 16384]
                                  [--precision fp32|bf16|bf16x3]          (needs the MI355X: the plan is RECORDED, not re-derived)
 
-Runs ONE rollout forward (catppo_policy_act_rng on `--envs` rows) and ONE optimiser step
+Runs ONE rollout forward (catppo_policy_step on `--envs` rows) and ONE optimiser step
 (catppo_ppo_minibatch_step_packed on `--minibatch` rows) on random data with catppo_plan_log switched on and prints what
 the library's dispatch code wrote at its decision sites: kernel, grid, and the rule that selected it.  `--all` walks the
 BASELINE shapes (profiles/r5_explain_plan.txt is this output)."""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # final validation + profile refresh: everything that gets committed under profiles/ is produced here
 set -u
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 REPO=$PWD
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
@@ -21,10 +21,13 @@ python tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq1_cfg2.csv" "$OUT/${TAG}_pmc_s
 # the reduced-precision modes: kernel trace + FETCH / WRITE passes (round 5: they had `traffic: null`)
 SQ_PASSES=0 BENCH_ARGS="--mlp-precision bf16x3" bash tools/profile_bench.sh cfg2 $TAG _bf16x3 >> "$OUT/final_profile.log" 2>&1
 SQ_PASSES=0 bash tools/profile_bench.sh cfg5 $TAG >> "$OUT/final_profile.log" 2>&1
+# round 6: one rank's share of cfg3 at 8 ranks (2048-row minibatches: step16_kernel + dw_multi_kernel + fold), with the SQ passes
+bash tools/profile_bench.sh cfg3_shard $TAG >> "$OUT/final_profile.log" 2>&1
+python tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq1_cfg3_shard.csv" "$OUT/${TAG}_pmc_sq2_cfg3_shard.csv" > "$OUT/${TAG}_pmc_sq_summary_cfg3_shard.json" 2>/dev/null
+cp "$OUT/${TAG}_pmc_traffic_cfg3_shard.json" "$OUT/${TAG}_bench_cfg3_shard_kernel_stats.csv" profiles/ 2>/dev/null
 mkdir -p profiles && cp "$OUT/${TAG}_pmc_traffic_cfg2.json" "$OUT/${TAG}_bench_cfg2_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg2_bf16x3.json" \
    "$OUT/${TAG}_bench_cfg2_bf16x3_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg5.json" "$OUT/${TAG}_bench_cfg5_kernel_stats.csv" profiles/ 2>/dev/null
 bash tools/gpu_trace_one.sh reference $TAG > /dev/null 2>&1
-bash tools/gpu_trace_one.sh cfg3_shard $TAG > /dev/null 2>&1
 echo "== bench lines ($(( $(date +%s) - T0 )) s)"
 timeout 400 python bench.py 2> "$OUT/${TAG}_bench_cfg2.err" | tail -1 > "$OUT/${TAG}_bench_cfg2.json"
 B="timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
@@ -40,6 +43,10 @@ timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline 2> "
 echo "== three more default lines back to back (run-to-run spread) ($(( $(date +%s) - T0 )) s)"
 : > "$OUT/${TAG}_bench_cfg2_repeats.jsonl"
 for i in 1 2 3; do timeout 300 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 >> "$OUT/${TAG}_bench_cfg2_repeats.jsonl"; done
+if [ -f tools/bin/libcatppo_s16tl.so ]; then
+  echo "== step16 timeline ($(( $(date +%s) - T0 )) s)"
+  (for net in ref cfg2; do echo "==== $net"; CATPPO_LIB=$PWD/tools/bin/libcatppo_s16tl.so timeout 120 python tools/step16_timeline.py 2048 $net; done) 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_step16_timeline.txt"
+fi
 if [ "${SKIP_TESTS:-0}" != "1" ] && [ -f tools/bin/libcatppo_fftl.so ]; then
   echo "== rows_fwd timeline ($(( $(date +%s) - T0 )) s)"
   (CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 48 2; CATPPO_LIB=$PWD/tools/bin/libcatppo_fftl.so timeout 120 python tools/rows_fwd_timeline.py 16384 240 2) 2>&1 | grep -v amdgpu.ids > "$OUT/${TAG}_rows_fwd_timeline.txt"

@@ -12,7 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel", "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel")
+GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel", "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel", "step16_kernel", "dw_multi_kernel")
 
 
 def per_launch(path):
