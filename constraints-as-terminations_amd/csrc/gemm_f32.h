@@ -49,6 +49,10 @@ constexpr int BK = 16;             // default contraction slab; kernels take it 
 #define GEMM_STAGE_PARTIAL 1       // 0: split-K partials stored with single-dword write-through stores (rounds 1-5) - A/B builds
 #endif
 
+#ifndef GEMM_ROW_SWIZZLE
+#define GEMM_ROW_SWIZZLE 1         // 0: K-contiguous staging rows in thread order (2-way ds_write_b128 conflicts, rounds 1-5) - A/B builds
+#endif
+
 #ifndef GEMM_PACKED
 #define GEMM_PACKED 1              // 0: bf16 / split-bf16 operands converted at every use (rounds 1-4) - A/B builds
 #endif
@@ -364,6 +368,13 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   }
 
   float4 ra[A_LD4], rb[B_LD4];
+  // K-contiguous staging, 16-k slabs: WHICH row of the tile a thread brings in.  Thread quad f / 4 takes row krow(f / 4) =
+  // f / 4 with bits 0 and 2 exchanged, so the 8 consecutive lanes of one ds_write_b128 group hold rows r and r + 4 (80-B row
+  // stride: 320 B apart = 16 banks of the 32 a b128 write sees - disjoint) instead of r and r + 1 (80 B apart: the second
+  // row's last quad wrapped onto the first row's first, a 2-way conflict on every write: SQ_LDS_BANK_CONFLICT 0.27-0.34 per
+  // LDS-active cycle through round 5).  The LDS image, the set of addresses of every global load instruction (a wave still
+  // covers 16 whole rows) and therefore every result are unchanged.  GEMM_ROW_SWIZZLE=0: rounds 1-5 (A/B builds).
+  auto krow = [](int r) { return (GEMM_ROW_SWIZZLE && KQ == 4) ? ((r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1)) : r; };
 
   // Interior tiles (every row / column of the tile in bounds: all of them at the BASELINE shapes) take branch-free
   // loads through per-thread pointers that advance by one slab per iteration; edge tiles and the last, partial slab
@@ -378,13 +389,13 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
 #pragma unroll
   for (int q = 0; q < A_LD4; ++q) {
     const int f = tid + q * 256;
-    aoff[q] = 4u * (A_KC ? (uint32_t)(f / KQ) * (uint32_t)p.lda + 4u * (f % KQ)
+    aoff[q] = 4u * (A_KC ? (uint32_t)krow(f / KQ) * (uint32_t)p.lda + 4u * (f % KQ)
                          : (uint32_t)(f / (BM / 4)) * (uint32_t)p.lda + 4u * (f % (BM / 4)));
   }
 #pragma unroll
   for (int q = 0; q < B_LD4; ++q) {
     const int f = tid + q * 256;
-    boff[q] = 4u * (B_KC ? (uint32_t)(f / KQ) * (uint32_t)p.ldb + 4u * (f % KQ)
+    boff[q] = 4u * (B_KC ? (uint32_t)krow(f / KQ) * (uint32_t)p.ldb + 4u * (f % KQ)
                          : (uint32_t)(f / (BN / 4)) * (uint32_t)p.ldb + 4u * (f % (BN / 4)));
   }
   const int64_t a_step = 4 * (A_KC ? (int64_t)1 : (int64_t)p.lda), b_step = 4 * (B_KC ? (int64_t)1 : (int64_t)p.ldb);   // bytes per unit of k
@@ -402,7 +413,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
       const int f = tid + q * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (A_KC) {
-        const int r = f / KQ, kq = f % KQ;
+        const int r = krow(f / KQ), kq = f % KQ;
         const int gi = i0 + r;
         if (gi < p.I) v = *reinterpret_cast<const float4*>(op.A + (int64_t)gi * p.lda + k0 + 4 * kq);
       } else {
@@ -417,7 +428,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
       const int f = tid + q * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (B_KC) {
-        const int r = f / KQ, kq = f % KQ;
+        const int r = krow(f / KQ), kq = f % KQ;
         const int gj = j0 + r;
         if (gj < p.J) v = *reinterpret_cast<const float4*>(op.B + (int64_t)gj * p.ldb + k0 + 4 * kq);
       } else {
@@ -436,7 +447,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
     for (int q = 0; q < A_LD4; ++q) {
       const int f = tid + q * 256;
       if (A_KC) {
-        const int r = f / KQ, kq = f % KQ;
+        const int r = krow(f / KQ), kq = f % KQ;
         *reinterpret_cast<float4*>(a + r * KC_STRIDE + 4 * kq) = ra[q];
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
@@ -447,7 +458,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
     for (int q = 0; q < B_LD4; ++q) {
       const int f = tid + q * 256;
       if (B_KC) {
-        const int r = f / KQ, kq = f % KQ;
+        const int r = krow(f / KQ), kq = f % KQ;
         *reinterpret_cast<float4*>(b + r * KC_STRIDE + 4 * kq) = rb[q];
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);

@@ -356,16 +356,19 @@ __global__ __launch_bounds__(head_waves<CPL>() * 64, (CPL <= 4 ? 4 : 2)) void he
 // -DFWD_HEAD_TL (tools/fwd_head_timeline.py): thread 0 of every workgroup stamps the shader clock at the step boundaries
 #ifdef FWD_HEAD_TL
 __device__ unsigned long long* g_fhtl;    // [2 nets][1024 workgroups][8 stamps]
-#define FH_TL(i) do { if (threadIdx.x == 0 && g_fhtl) g_fhtl[(blockIdx.z * 1024 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
+#define FH_TL(i) do { if (threadIdx.x == 0 && g_fhtl) g_fhtl[(net * 1024 + blockIdx.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define FH_TL(i) do { } while (0)
 #endif
 
+#ifndef FWD_HEAD_LEAN_CRITIC
+#define FWD_HEAD_LEAN_CRITIC 1     // 0: the critic's head steps on the matrix pipe like the actor's, critic workgroups dispatched first (rounds 2-5)
+#endif
 #ifndef FWD_HEAD_MFMA16
 #define FWD_HEAD_MFMA16 1          // 0: steps A and C on v_mfma_f32_32x32x2_f32 with the 16 head outputs padded to 32 (rounds 2-4)
 #endif
 template <int HL>
-constexpr size_t fwd_head_lds_floats() { return (size_t)64 * (HL + gemm::kLdsTilePad) + 64 * 16 + 64 * 16 + 64 * 8 + 4; }
+constexpr size_t fwd_head_lds_floats() { return (size_t)64 * (HL + gemm::kLdsTilePad) + 64 * 16 + 64 * 16 + 64 * 8 + 4 + HL; }
 
 template <int HL, int PREC = 0>      // PREC: operand precision of the hidden-layer GEMM (gemm_body); the head products stay fp32
 __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const HeadArgs g) {   // two workgroups per CU
@@ -380,7 +383,13 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   float* sMu = sG + BM * 16;            // [64][16]   head outputs, later the per-row d loss / d logstd_k terms
   float* sD = sMu + BM * 16;            // [64][8]    per-row diagnostics {pg, v, ent, -, kl, old_kl, clipfrac, -}
   float* s_adv = sD + BM * 8;           // [2]        advantage mean, std + 1e-8
-  const int net = blockIdx.z;           // 0 critic, 1 actor (Params::op order)
+  [[maybe_unused]] float* sW = s_adv + 4;   // [HL]   lean critic epilogue: the value head's weight row
+  // Round 6: the ACTOR workgroups are dispatched first (blockIdx.z = 0).  The two workgroups of a CU - the actor's and the
+  // critic's tile of the same 64 rows - drift apart by themselves: the one dispatched first wins the matrix pipe, ends its main
+  // loop ~8 us ahead and runs its epilogue under the rest of the partner's loop; the epilogue of the SECOND one is exposed
+  // (13.8 us of the launch's 57 in round 5, profiles/r5_fwd_head_timeline.txt).  So the second one is now the critic, whose
+  // single head output needs no matrix instruction (the lean epilogue below).
+  const int net = FWD_HEAD_LEAN_CRITIC ? 1 - (int)blockIdx.z : (int)blockIdx.z;           // 0 critic, 1 actor (Params::op order)
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int A = g.A;
@@ -390,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   const int rows = (int)((g.M - i0) < BM ? (g.M - i0) : BM);
   const int NS = 2 * A + 1 + kHeadDiag;
 
+#if !FWD_HEAD_LEAN_CRITIC
   if (net == 1 && tid < 64) {           // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
     if (g.hp.norm_adv && g.adv_stats == nullptr) {
       double a1 = 0.0, a2 = 0.0;
@@ -413,11 +423,13 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
     }
   }
 
+#endif
   FH_TL(0);
   const float* Wh = net == 1 ? g.W4a : g.W4c;          // [KH][HL] head weights of this network
   const int KH = net == 1 ? A : 1;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   const int wm = q >> 1, wn = q & 1;
+  const bool mat = !(FWD_HEAD_LEAN_CRITIC && net == 0);      // this workgroup's head steps run on the matrix pipe
   // Everything the epilogue reads from global memory is requested here, ahead of the main loop: the head weights in
   // the operand layouts of steps A and B (rows past KH zero) and the gathered scalars of the row this thread will
   // work on (row math: four threads per row, thread part pp owns the action dims pp, pp+4, pp+8, pp+12).
@@ -429,7 +441,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   float4 bw[KQ / 16];          // step A: Wh[c16][q KQ + 16 blk + 4 g4 + s], MFMA (blk, s) contracts k = 16 blk + 4 g + s over g
 #pragma unroll
   for (int kb = 0; kb < KQ / 16; ++kb)
-    bw[kb] = c16 < KH ? *reinterpret_cast<const float4*>(Wh + c16 * HL + q * KQ + 16 * kb + 4 * g4) : zero4;
+    bw[kb] = mat && c16 < KH ? *reinterpret_cast<const float4*>(Wh + c16 * HL + q * KQ + 16 * kb + 4 * g4) : zero4;
 #else
   float4 bw[KQ / 8];
 #pragma unroll
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
 #pragma unroll
       for (int sx = 0; sx < 4; ++sx) {
         const int kk = 8 * blk + 4 * h + sx;
-        bwB[tn][blk][sx] = kk < KH ? Wh[kk * HL + wn * (HL / 2) + 32 * tn + l31] : 0.0f;
+        bwB[tn][blk][sx] = mat && kk < KH ? Wh[kk * HL + wn * (HL / 2) + 32 * tn + l31] : 0.0f;
       }
   const int rr = tid >> 2, pp = tid & 3;               // row math: row, part
   const bool rvalid = rr < rows;
@@ -462,8 +474,138 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   }
   const float rbc = g.b4c[0], rvv = g.vrms_var[0], rvm = g.vrms_mean[0];
 
-  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, PREC, 1>(p, tile, blockIdx.z, smem);
+  constexpr bool kLean = FWD_HEAD_LEAN_CRITIC != 0;
+  if (kLean && net == 0 && tid < HL / 4)               // (sW lies beyond the slab buffers; the main loop's barriers publish it)
+    *reinterpret_cast<float4*>(sW + 4 * tid) = *reinterpret_cast<const float4*>(g.W4c + 4 * tid);
+
+  gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, PREC, 1>(p, tile, net, smem);
   FH_TL(1);
+#if FWD_HEAD_LEAN_CRITIC
+  // (round 6: behind the main loop - in front of it the actor's four waves waited ~1.5 us for wave 0 at the loop's first barrier;
+  //  s_adv is read by the row math, two barriers further down)
+  if (net == 1 && tid < 64) {           // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
+    if (g.hp.norm_adv && g.adv_stats == nullptr) {
+      double a1 = 0.0, a2 = 0.0;
+      for (int b = lane; b < g.n_adv_part; b += 64) {
+        a1 += g.adv_part[2 * b];
+        a2 += g.adv_part[2 * b + 1];
+      }
+      a1 = wave_sum_d(a1);
+      a2 = wave_sum_d(a2);
+      if (lane == 0) {
+        const double n = (double)g.M;
+        const double mean = a1 / n;
+        double var = (a2 - n * mean * mean) / (n - 1.0);   // NaN for n == 1, like torch.std()
+        if (var < 0.0) var = 0.0;
+        s_adv[0] = (float)mean;
+        s_adv[1] = (float)sqrt(var) + 1e-8f;
+      }
+    } else if (lane == 0) {
+      s_adv[0] = g.adv_stats ? g.adv_stats[0] : 0.0f;
+      s_adv[1] = g.adv_stats ? g.adv_stats[1] : 1.0f;
+    }
+  }
+
+#endif
+
+  const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
+  const int prow = net == 1 ? tile : RB + tile;
+  if (kLean && net == 0) {
+    // ---- lean critic epilogue (round 6): ONE head output - steps A, C, B as plain fp32 FMA chains in exactly the order the
+    //      matrix instructions walk them (v_mfma_f32_16x16x4_f32 / 32x32x2 = one FMA chain per element in k order,
+    //      tools/mfma16_probe.hip), so every value is bit-identical to the matrix form; no operand padding (15 of 16 head
+    //      columns were zeros), no partial-sum round trips through LDS, two workgroup barriers instead of six.
+    __syncthreads();                                     // H tile complete
+    // A: v = H[r,:] . w.  Four threads per row, thread part pp = contraction quarter pp (what wave pp did): k = pp KQ + 16 kb
+    //    + 4 g + s in the order kb, s, g; quarters combined (q0 + q1) + (q2 + q3)
+    float vsum;
+    {
+      float acc = 0.0f;
+      const float* hrow = Hs + rr * LD + pp * KQ;
+      const float* wq = sW + pp * KQ;
+#pragma unroll
+      for (int kb = 0; kb < KQ / 16; ++kb) {
+        float hv[4][4], wv[4][4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const float4 h4 = *reinterpret_cast<const float4*>(hrow + 16 * kb + 4 * gq);
+          const float4 w4 = *reinterpret_cast<const float4*>(wq + 16 * kb + 4 * gq);
+          hv[gq][0] = h4.x, hv[gq][1] = h4.y, hv[gq][2] = h4.z, hv[gq][3] = h4.w;
+          wv[gq][0] = w4.x, wv[gq][1] = w4.y, wv[gq][2] = w4.z, wv[gq][3] = w4.w;
+        }
+#pragma unroll
+        for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) acc = __builtin_fmaf(hv[gq][sx], wv[gq][sx], acc);
+      }
+      const float t2 = acc + __shfl_xor(acc, 1, 64);     // q0 + q1 | q2 + q3
+      vsum = t2 + __shfl_xor(t2, 2, 64);
+    }
+    FH_TL(2);
+    // row math (value loss, ppo.py:325-338): thread part 0 of the row
+    {
+      float dg1 = 0.0f, gm0 = 0.0f;
+      if (rvalid && pp == 0) {
+        const bool clip_vloss = g.hp.clip_vloss != 0;
+        const float vden = sqrtf(rvv + 1e-8f), vmean = rvm;
+        const float vf_half = g.hp.vf_coef * 0.5f;
+        const float R = rs0, Vo = rs1;
+        const float v = vsum + rbc;
+        const float nv = (v - vmean) / vden;         // value_rms(newvalue, update=False)
+        const float e1 = nv - R;
+        const float vl1 = e1 * e1;
+        const float dl = nv - Vo;
+        const float cl = dl < -clipc ? -clipc : (dl > clipc ? clipc : dl);
+        const float e2 = (Vo + cl) - R;
+        const float vl2 = e2 * e2;
+        if (g.branch_out != nullptr) g.branch_out[g.M + ri] = clip_code(dl, 0.0f, clipc) | ((vl1 > vl2 ? 1 : (vl1 < vl2 ? 2 : 0)) << 2);
+        const bool in2 = dl >= -clipc && dl <= clipc;
+        const float dnv_c = vl1 > vl2 ? 2.0f * e1 : (vl1 < vl2 ? (in2 ? 2.0f * e2 : 0.0f) : e1 + (in2 ? e2 : 0.0f));
+        const float vl = clip_vloss ? (vl1 > vl2 ? vl1 : vl2) : vl1;
+        const float dnv = clip_vloss ? dnv_c : 2.0f * e1;
+        dg1 = 0.5f * vl;
+        gm0 = vf_half * dnv * invM / vden;         // d loss / d v_i  (slot 0)
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) sG[rr * 16 + pp + 4 * kk] = (pp == 0 && kk == 0) ? gm0 : 0.0f, sMu[rr * 16 + pp + 4 * kk] = 0.0f;
+      if (pp == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sD[rr * 8 + e] = e == 1 ? dg1 : 0.0f;
+      }
+    }
+    __syncthreads();
+    FH_TL(3);
+    // C: dW4c[c] = sum_r G[r] H[r][c], one thread per column, rows ascending (the matrix form's chain: row 4 s + g)
+    if (tid < HL) {
+      float acc = 0.0f;
+#pragma unroll 8
+      for (int r = 0; r < BM; ++r) acc = __builtin_fmaf(sG[r * 16], Hs[r * LD + tid], acc);
+      g.part_w[(int64_t)prow * (A + 1) * HL + (int64_t)A * HL + tid] = acc;      // row A = dW4c
+    }
+    FH_TL(4);
+    // B + stream-out: dZ[r][c] = fl(G[r] w[c]) * elu'(H[r][c]); a wave writes whole rows (1 KB / 512 B contiguous)
+    {
+      constexpr int C4 = HL / 4;                 // float4 chunks per row
+      constexpr int RPP = 256 / C4;              // rows per pass of the workgroup
+      const int c4 = tid % C4, r_in = tid / C4;
+      const float4 w4 = *reinterpret_cast<const float4*>(sW + 4 * c4);
+      const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll 4
+      for (int rb = 0; rb < BM; rb += RPP) {
+        const int r = rb + r_in;
+        if (r < rows) {
+          const float gr = sG[r * 16];
+          const float4 h4 = *reinterpret_cast<const float4*>(Hs + r * LD + 4 * c4);
+          const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
+          float o[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(gr, wv[e], 0.0f) * (hv[e] > 0.0f ? 1.0f : hv[e] + 1.0f);
+          store_vec_wt<4>(g.dZc + (i0 + r) * HL + 4 * c4, o);
+        }
+      }
+    }
+    FH_TL(5);
+  } else {
 
   // ---- A: head outputs.  MFMA step (blk, s) of lane-half h contracts k = 8 blk + 4 h + s - the same permutation on
   //         both operands (gemm_body's K-contiguous fragments)
@@ -542,7 +684,6 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
 #endif
 
   FH_TL(2);
-  const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
   // ---- row math: four threads per row
   {
     const int r = rr;
@@ -629,7 +770,6 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
 
   FH_TL(3);
   // ---- C: head weight gradient of the tile, dWh[k][c] = sum_r G[r][k] H[r][c]; wave q owns TNC column tiles
-  const int prow = net == 1 ? tile : RB + tile;
   {
 #if FWD_HEAD_MFMA16
     // D tile = 16 head outputs x 16 columns; contraction over the tile's 64 rows, 4 per instruction (row 4 step + g4)
@@ -730,6 +870,7 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
       }
     }
   }
+  }   // matrix-form epilogue
   // ---- scalars of the tile: bias / logstd gradients, diagnostics.  16 row groups of 4 rows, combined in fixed order
   //      through LDS (the H / dZ tile is free again once every row has been streamed out)
   __syncthreads();
