@@ -399,7 +399,6 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   const int rows = (int)((g.M - i0) < BM ? (g.M - i0) : BM);
   const int NS = 2 * A + 1 + kHeadDiag;
 
-#if !FWD_HEAD_LEAN_CRITIC
   if (net == 1 && tid < 64) {           // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
     if (g.hp.norm_adv && g.adv_stats == nullptr) {
       double a1 = 0.0, a2 = 0.0;
@@ -423,7 +422,6 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
     }
   }
 
-#endif
   FH_TL(0);
   const float* Wh = net == 1 ? g.W4a : g.W4c;          // [KH][HL] head weights of this network
   const int KH = net == 1 ? A : 1;
@@ -480,33 +478,6 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
 
   gemm::gemm_body<BM, HL, true, true, gemm::EPI_BIAS_ELU_LDS, gemm::BK, PREC, 1>(p, tile, net, smem);
   FH_TL(1);
-#if FWD_HEAD_LEAN_CRITIC
-  // (round 6: behind the main loop - in front of it the actor's four waves waited ~1.5 us for wave 0 at the loop's first barrier;
-  //  s_adv is read by the row math, two barriers further down)
-  if (net == 1 && tid < 64) {           // advantage statistics over the minibatch (ppo.py:314-318): mean, unbiased std
-    if (g.hp.norm_adv && g.adv_stats == nullptr) {
-      double a1 = 0.0, a2 = 0.0;
-      for (int b = lane; b < g.n_adv_part; b += 64) {
-        a1 += g.adv_part[2 * b];
-        a2 += g.adv_part[2 * b + 1];
-      }
-      a1 = wave_sum_d(a1);
-      a2 = wave_sum_d(a2);
-      if (lane == 0) {
-        const double n = (double)g.M;
-        const double mean = a1 / n;
-        double var = (a2 - n * mean * mean) / (n - 1.0);   // NaN for n == 1, like torch.std()
-        if (var < 0.0) var = 0.0;
-        s_adv[0] = (float)mean;
-        s_adv[1] = (float)sqrt(var) + 1e-8f;
-      }
-    } else if (lane == 0) {
-      s_adv[0] = g.adv_stats ? g.adv_stats[0] : 0.0f;
-      s_adv[1] = g.adv_stats ? g.adv_stats[1] : 1.0f;
-    }
-  }
-
-#endif
 
   const float clipc = g.hp.clip_coef, invM = g.hp.inv_global_batch;
   const int prow = net == 1 ? tile : RB + tile;
