@@ -326,6 +326,164 @@ struct PkLoop {
   }
 };
 
+
+// ---- bf16-STORED operands (round 6, "act16": BASELINE configs[4], operand precision 1) ---------------------------------------
+// With bf16 matrix operands the optimiser-step group is HBM-bound (677 MB per 16384-row group at 5 TB/s)
+// while every activation H and every dZ crossed HBM as fp32 only to be rounded to bf16 where a GEMM consumed it.  Storing them
+// AS bf16 rounds at the producer instead of the consumer - the GEMM operands are the same bf16 values, every forward value
+// agrees to fp32 rounding (the k of an instruction sit in other operand slots: another internal summation order); what differs
+// beyond that: elu'(H) and the bias-gradient column sums see the rounded values - and halves the activation traffic.  Round 5 built
+// this once with 8-byte loads (4 bf16 per lane) and found it slower; here every lane still moves 16 bytes per load:
+//   K-contiguous operands (forward, data gradient): a [rows][K] bf16 matrix IS a [rows][K / 2] float matrix for the staging
+//       code of gemm_body - same loads, same LDS image, same b128 fragment reads - whose 16-"float" slab is a 32-k slab; a
+//       lane's float4 fragment (floats 8 blk + 4 h ..) is the 8 bf16 k = 16 blk + 8 h + e one v_mfma_f32_32x32x16_bf16 wants.
+//       The host passes lda / ldb / Kc of such a problem in FLOAT units (PREC 3; weights come as bf16 copies, W and W^T).
+//   I-contiguous operands (weight gradient, contraction over the minibatch rows): IILoop16 below - 32-k slabs, a thread loads
+//       8 consecutive rows (16 B) at k and k + 1 and interleaves them into the k-pair plane [16 k pairs][rows] of u32 the
+//       split-bf16 loop (PkLoop) reads: fragment = four ds_read_b32.  B may be an fp32 matrix (the observations of the first
+//       layer: PREC 5): float4 of four rows at k, k + 1, packed.
+// PREC:  3 = both operands bf16-stored (outputs / aux bf16 too: EPI_BIAS_ELU, EPI_MUL_DELU)   4 = fp32-stored operands rounded at
+//        use (PREC 1's loop) with a bf16-stored OUTPUT (first layer forward)   5 = weight gradient with an fp32-stored B.
+template <int BM, int BN, int EPI, bool B16, int WAVES_M>
+struct IILoop16 {
+  static constexpr int WAVES_N = 4 / WAVES_M;
+  static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+  static constexpr int A_PLANE = 16 * BM, B_PLANE = 16 * BN;         // u32 per buffer
+  static_assert(BM <= 128 && BN <= 128 && (B16 || BN <= 64), "one staging job per thread and operand");
+  static_assert(EPI == EPI_PARTIAL, "the weight-gradient loop");
+
+  static __device__ __forceinline__ void run(const Params& p, const Operands& op, const int i0, const int j0,
+                                             const int k_begin, const int k_end, const bool do_db,
+                                             float* __restrict__ smem, f32x16 (&acc)[TM][TN], float& dbsum) {
+    uint32_t* As = reinterpret_cast<uint32_t*>(smem);                  // [2][A_PLANE]
+    uint32_t* Bs = As + 2 * A_PLANE;                                   // [2][B_PLANE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = WAVES_M == 2 ? wave >> 1 : 0, wn = WAVES_M == 2 ? wave & 1 : wave;
+    const int l31 = lane & 31, h = lane >> 5;
+    const uint16_t* A16 = reinterpret_cast<const uint16_t*>(op.A);
+    const uint16_t* B16p = reinterpret_cast<const uint16_t*>(op.B);
+    const int n_slabs = (k_end - k_begin + 31) / 32;
+    // staging jobs: A (and a bf16-stored B): (k pair kp, row octet io); fp32-stored B: (k pair, row quad)
+    const bool a_job = tid < 2 * BM;
+    const int a_kp = tid / (BM / 8), a_io = tid % (BM / 8);
+    const bool b_job = B16 ? tid < 2 * BN : tid < 4 * BN;
+    const int b_kp = B16 ? tid / (BN / 8) : tid / (BN / 4), b_io = B16 ? tid % (BN / 8) : tid % (BN / 4);
+    const bool a_in = i0 + 8 * a_io + 7 < p.I;
+    const bool b_in = B16 ? j0 + 8 * b_io + 7 < p.J : j0 + 4 * b_io + 3 < p.J;
+    u32x4 ra0, ra1, rb0, rb1;
+    float dbv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // exact fp32 column sums of the (bf16) values of A this thread staged
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    auto load = [&](int s) {
+      const int k0 = k_begin + 32 * s;
+      ra0 = z4, ra1 = z4, rb0 = z4, rb1 = z4;
+      if (a_job && a_in) {
+        const int gk = k0 + 2 * a_kp;
+        const uint16_t* src = A16 + (int64_t)gk * p.lda + i0 + 8 * a_io;
+        if (gk < k_end) ra0 = *reinterpret_cast<const u32x4*>(src);
+        if (gk + 1 < k_end) ra1 = *reinterpret_cast<const u32x4*>(src + p.lda);
+      }
+      if (b_job && b_in) {
+        const int gk = k0 + 2 * b_kp;
+        if (B16) {
+          const uint16_t* src = B16p + (int64_t)gk * p.ldb + j0 + 8 * b_io;
+          if (gk < k_end) rb0 = *reinterpret_cast<const u32x4*>(src);
+          if (gk + 1 < k_end) rb1 = *reinterpret_cast<const u32x4*>(src + p.ldb);
+        } else {
+          const float* src = op.B + (int64_t)gk * p.ldb + j0 + 4 * b_io;
+          if (gk < k_end) rb0 = *reinterpret_cast<const u32x4*>(src);
+          if (gk + 1 < k_end) rb1 = *reinterpret_cast<const u32x4*>(src + p.ldb);
+        }
+      }
+      if (do_db) {                                                     // workgroup-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dbv[2 * j] += __uint_as_float(ra0[j] << 16) + __uint_as_float(ra1[j] << 16);
+          dbv[2 * j + 1] += __uint_as_float(ra0[j] & 0xffff0000u) + __uint_as_float(ra1[j] & 0xffff0000u);
+        }
+      }
+    };
+    // {x(k, r), x(k + 1, r)} per row: low half = even k
+    auto interleave = [](const u32x4& e, const u32x4& o, u32x4& lo, u32x4& hi) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        lo[2 * j] = (e[j] & 0xffffu) | (o[j] << 16), lo[2 * j + 1] = (e[j] >> 16) | (o[j] & 0xffff0000u);
+        hi[2 * j] = (e[j + 2] & 0xffffu) | (o[j + 2] << 16), hi[2 * j + 1] = (e[j + 2] >> 16) | (o[j + 2] & 0xffff0000u);
+      }
+    };
+    auto store = [&](int buf) {
+      if (a_job) {
+        u32x4 lo, hi;
+        interleave(ra0, ra1, lo, hi);
+        uint32_t* d = As + buf * A_PLANE + a_kp * BM + 8 * a_io;
+        *reinterpret_cast<u32x4*>(d) = lo, *reinterpret_cast<u32x4*>(d + 4) = hi;
+      }
+      if (b_job) {
+        if (B16) {
+          u32x4 lo, hi;
+          interleave(rb0, rb1, lo, hi);
+          uint32_t* d = Bs + buf * B_PLANE + b_kp * BN + 8 * b_io;
+          *reinterpret_cast<u32x4*>(d) = lo, *reinterpret_cast<u32x4*>(d + 4) = hi;
+        } else {
+          u32x4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = pk_bf16(__uint_as_float(rb0[j]), __uint_as_float(rb1[j]));
+          *reinterpret_cast<u32x4*>(Bs + buf * B_PLANE + b_kp * BN + 4 * b_io) = v;
+        }
+      }
+    };
+    if (n_slabs > 0) {
+      load(0);
+      store(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < n_slabs; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < n_slabs) load(s + 1);                                // in flight under the MFMAs below
+      const uint32_t* a = As + cur * A_PLANE;
+      const uint32_t* b = Bs + cur * B_PLANE;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        bf16x8 pa[TM], pb[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) {
+          u32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = a[(8 * m + 4 * h + i) * BM + wm * WM + t * 32 + l31];
+          pa[t] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          u32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = b[(8 * m + 4 * h + i) * BN + wn * WN + t * 32 + l31];
+          pb[t] = __builtin_bit_cast(bf16x8, v);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[tm], pb[tn], acc[tm][tn], 0, 0, 0);
+      }
+      if (s + 1 < n_slabs) store(cur ^ 1);
+      __syncthreads();
+    }
+    if (do_db) {                                                       // workgroup-uniform; the planes are free
+      if (a_job) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) smem[a_kp * BM + 8 * a_io + e] = dbv[e];
+      }
+      __syncthreads();
+      if (tid < BM) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int kp = 0; kp < 16; ++kp) sum += smem[kp * BM + tid];
+        dbsum = sum;
+      }
+      __syncthreads();
+    }
+  }
+};
+
 // One workgroup's tile.  `wg` = tile index inside the problem (j fastest), `bz` = net + nets * split; both come from
 // xcd_tile_of.
 // WAVES_M: the four waves tile the workgroup's output as WAVES_M x (4 / WAVES_M); 2 x 2 by default, 1 x 4 for wide flat
@@ -486,7 +644,13 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   // sits on the HBM roofline, and the planes' two-row loads cost it 1.4 us; (b) 64-row I-contiguous tiles (the first
   // layer's latency-bound weight gradient: only half the threads have a (k pair, row quad) job, 13.0 -> 19.0 us).
   constexpr bool kPacked = PREC == 2 && GEMM_PACKED && BK == 16 && (A_KC || BM >= 128) && (B_KC || BN >= 128);
-  if constexpr (!kPacked) {
+  // bf16-STORED operands (act16, see IILoop16): the weight-gradient loop of its own / the K-contiguous loop on reinterpreted slabs
+  constexpr bool kSrc16II = (PREC == 3 || PREC == 5) && !A_KC && !B_KC;
+  constexpr bool kSrc16KK = PREC == 3 && A_KC && B_KC;
+  static_assert(PREC <= 2 || PREC == 4 || kSrc16II || kSrc16KK, "operand layouts of the bf16-stored modes");
+  static_assert(PREC <= 2 || BK == 16, "bf16-stored modes: 16-float (32-k) slabs");
+  constexpr bool OUT16 = (PREC == 3 || PREC == 4) && (EPI == EPI_BIAS_ELU || EPI == EPI_MUL_DELU);     // C (and aux) stored as bf16
+  if constexpr (!kPacked && !kSrc16II) {
     if (n_slabs > 0) {
       gload(k_begin, std::false_type{});
       lstore(0);
@@ -496,7 +660,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
 
   // data gradient: the activation the epilogue multiplies with does not depend on the contraction; with one
   // accumulator tile per wave (16 values per lane) fetch it now so its HBM latency hides behind the main loop
-  constexpr bool AUX_EARLY = EPI == EPI_MUL_DELU && TM * TN <= 2;
+  constexpr bool AUX_EARLY = EPI == EPI_MUL_DELU && TM * TN <= 2 && PREC != 3;
   float auxv[AUX_EARLY ? TM * TN : 1][16];
   if constexpr (AUX_EARLY) {
 #pragma unroll
@@ -607,6 +771,25 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][tm][q], bf[1][tn][q], acc[tm][tn], 0, 0, 0);
       __syncthreads();
       continue;
+    } else if constexpr (kSrc16KK) {
+      // bf16-stored K-contiguous operands: a lane's float4 IS the 8 bf16 (k = 16 blk + 8 h + e) of one MFMA operand
+      using f32x4 = __attribute__((ext_vector_type(4))) float;
+#pragma unroll
+      for (int blk = 0; blk < BK / 8; ++blk) {
+        float af[TM][4], bf[TN][4];
+        frag_a(blk, af);
+        frag_b(blk, bf);
+        bf16x8 pa[TM], pb[TN];
+#pragma unroll
+        for (int t = 0; t < TM; ++t) pa[t] = __builtin_bit_cast(bf16x8, f32x4{af[t][0], af[t][1], af[t][2], af[t][3]});
+#pragma unroll
+        for (int t = 0; t < TN; ++t) pb[t] = __builtin_bit_cast(bf16x8, f32x4{bf[t][0], bf[t][1], bf[t][2], bf[t][3]});
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa[tm], pb[tn], acc[tm][tn], 0, 0, 0);
+      }
     } else if constexpr (PREC == 0) {
 #pragma unroll
       for (int blk = 0; blk < BK / 8; ++blk) {
@@ -686,6 +869,8 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   constexpr bool kPipedLoop = PREC == 0 && BK == 16 && GEMM_PIPE && A_KC && B_KC;
   if constexpr (kPacked) {
     PkLoop<BM, BN, A_KC, B_KC, EPI, PREC, WAVES_M>::run(p, op, i0, j0, k_begin, k_end, do_db, smem, acc, dbsum);
+  } else if constexpr (kSrc16II) {
+    IILoop16<BM, BN, EPI, PREC == 3, WAVES_M>::run(p, op, i0, j0, k_begin, k_end, do_db, smem, acc, dbsum);
   } else {
     if (kPipedLoop && interior && (k_end - k_begin) % BK == 0) main_loop(std::true_type{});
     else main_loop(std::false_type{});
@@ -748,7 +933,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
 #else
           v = elu_f(v + bias);
 #endif
-        } else if (EPI == EPI_MUL_DELU) {
+        } else if (EPI == EPI_MUL_DELU && PREC != 3) {   // (bf16-stored aux: multiplied in the row phase below, 8 columns per 16-B load)
           float hact;
           if constexpr (AUX_EARLY) {
             hact = auxv[tm * TN + tn][r];
@@ -773,7 +958,40 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
           }
         }
       }
-      if constexpr (STAGED) {
+      if constexpr (STAGED && OUT16) {
+        // bf16-stored output: a lane owns 8 consecutive columns of a row (two b128 reads of the patch, one 16-B store);
+        // 4 lanes = one 64-B row segment, 16 rows per instruction.  Data gradient: the aux activations (bf16-stored) arrive
+        // the same way and elu' is applied here.
+        __builtin_amdgcn_wave_barrier();
+        const int c8 = 8 * (lane & 3);
+        const int gj8 = j0 + wn * WN + tn * 32 + c8;
+        uint16_t* C16 = reinterpret_cast<uint16_t*>(Cout);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int lrow = it * 16 + (lane >> 2);
+          const int gi = i0 + wm * WM + tm * 32 + lrow;
+          const float4 q0 = *reinterpret_cast<const float4*>(stg + lrow * STG_LD + c8);
+          const float4 q1 = *reinterpret_cast<const float4*>(stg + lrow * STG_LD + c8 + 4);
+          float o[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+          if (gi < p.I && gj8 + 7 < p.J) {
+            if constexpr (EPI == EPI_MUL_DELU) {
+              const u32x4 hx = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(op.aux) + (int64_t)gi * p.ldaux + gj8);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const float h0 = __uint_as_float(hx[j] << 16), h1 = __uint_as_float(hx[j] & 0xffff0000u);
+                o[2 * j] *= h0 > 0.0f ? 1.0f : h0 + 1.0f;
+                o[2 * j + 1] *= h1 > 0.0f ? 1.0f : h1 + 1.0f;
+              }
+            }
+            u32x4 pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pk[j] = pk_bf16(o[2 * j], o[2 * j + 1]);
+            uint16_t* dstp = C16 + (int64_t)gi * p.ldc + gj8;
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dstp), "v"(pk) : "memory");
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else if constexpr (STAGED) {
         __builtin_amdgcn_wave_barrier();                         // LDS ops of a wave execute in order
         const int gj4 = j0 + wn * WN + tn * 32 + 4 * (lane & 7);  // 8 lanes x 16 B = one 128-B row segment
 #pragma unroll

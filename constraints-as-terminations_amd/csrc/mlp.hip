@@ -514,6 +514,12 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
   const int RB = (int)cdiv64(M, 64);
   const bool fused_head = fused_head_env && (HL == 128 || HL == 256) && nl >= 2 &&
                           L.in_dim[nl - 1] % gemm::BK == 0 && 2 * RB >= fused_head_min && A <= 15;
+  // Round 6, bf16 operands (BASELINE configs[4]): activations and dZ STORED as bf16, bf16 weight copies (gemm_f32.h "act16").
+  // Needs the fused head launch (the 64-row head_loss path reads fp32 activations) and the plain single-stream backward.
+  // CATPPO_ACT16=0: fp32-stored activations rounded at every use (rounds 2-5; A/B).
+  static const int act16_env = env_int("CATPPO_ACT16", 1);
+  const bool act16 = act16_env && shape->mfma_bf16 == 1 && fused_head && !ctx->use_side && ctx->grad_overlap != 1 && w.w16 != nullptr &&
+                     getenv("CATPPO_NO_PAIR") == nullptr;
   // Round 6: small minibatches (an env-sharded rank's 2048 rows, cfg1) - forward, heads, loss, head backward and the data
   // gradients of the hidden layers in ONE launch of 16-row workgroups (step16.h), then every layer's weight gradient in
   // one grouped launch (dw_multi_kernel) and the fold: 3 launches instead of 10.  CATPPO_STEP16=0 keeps the layer-wise
@@ -576,7 +582,47 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     static const int rows_fwd_min = env_int("CATPPO_ROWS_FWD_MIN_ROWS", 8192);
     FusedFwdArgs ra{};
     size_t rlds = 0;
-    if (rows_fwd_env && M >= rows_fwd_min && M <= (1 << 20) && nl - 1 <= 3 &&
+    if (act16) {
+      // bf16 copies of W_1 .. W_{nl-1} (as stored and transposed), then the layer-wise forward with bf16-stored activations
+      W16Segs ws16{};
+      int64_t tot = 0;
+      for (int net = 0; net < 2; ++net)
+        for (int l = 1; l < nl; ++l) {
+          const int i = ws16.n++;
+          ws16.off[i] = L.off_w[net][l], ws16.out[i] = shape->hidden[l], ws16.in[i] = L.in_dim[l];
+          ws16.first[i] = tot;
+          tot += (int64_t)shape->hidden[l] * L.in_dim[l];
+        }
+      ws16.first[ws16.n] = tot;
+      hipLaunchKernelGGL(w16_convert_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, params, w.w16, w.w16t, ws16);
+      for (int l = 0; l < nl - 1; ++l) {
+        Params pf{};
+        pf.xcd_legacy = xcd_legacy();
+        pf.nets = 2, pf.splits = 1;
+        pf.I = (int)M, pf.J = shape->hidden[l];
+        pf.ldc = shape->hidden[l];                           // bf16 elements
+        for (int net = 0; net < 2; ++net) {
+          pf.op[net].bias = params + L.off_b[net][l];
+          pf.op[net].C = w.H[net][l];
+          if (l == 0) {
+            pf.op[net].A = w.xmb, pf.op[net].B = params + L.off_w[net][0];
+          } else {
+            pf.op[net].A = w.H[net][l - 1];
+            pf.op[net].B = reinterpret_cast<const float*>(w.w16 + L.off_w[net][l]);
+          }
+        }
+        if (l == 0) {                                        // fp32-stored operands (observations, W_0), bf16-stored output
+          pf.Kc = L.in_dim[0], pf.lda = L.in_dim[0], pf.ldb = L.in_dim[0];
+          launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 4>(pf, s);
+        } else {                                             // bf16-stored operands: contraction sizes in FLOAT units
+          pf.Kc = L.in_dim[l] / 2, pf.lda = L.in_dim[l] / 2, pf.ldb = L.in_dim[l] / 2;
+          if (pf.J >= 128 && L.in_dim[l] >= 256) launch_gemm_prec<128, 128, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
+          else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
+        }
+      }
+      catppo_plan_note(ctx, "minibatch %lld rows, bf16-stored activations: w16_convert_kernel (%lld weights as bf16, stored + "
+                       "transposed) + %d layer-wise forward GEMM launches writing bf16", (long long)M, (long long)tot, nl - 1);
+    } else if (rows_fwd_env && M >= rows_fwd_min && M <= (1 << 20) && nl - 1 <= 3 &&
         rows_fwd_plan(shape, L, nl - 1, 64, &ra, &rlds)) {
       ra.x = w.xmb, ra.params = params, ra.M = M, ra.net0 = 0, ra.do_head = 0;
       for (int net = 0; net < 2; ++net)
@@ -622,7 +668,9 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       p.op[net].B = params + L.off_w[net][nl - 1];
       p.op[net].bias = params + L.off_b[net][nl - 1];
       p.op[net].C = nullptr;              // the activations of the last layer never leave the CU
+      if (act16) p.op[net].B = reinterpret_cast<const float*>(w.w16 + L.off_w[net][nl - 1]);
     }
+    if (act16) p.Kc /= 2, p.lda /= 2, p.ldb /= 2;      // bf16-stored operands: FLOAT units (gemm_f32.h)
     HeadArgs g{};
     g.dZc = w.dZ[0][nl - 1], g.dZa = w.dZ[1][nl - 1];
     g.W4c = params + L.off_w[0][nl], g.b4c = params + L.off_b[0][nl];
@@ -643,14 +691,16 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       kern<<<dim3(RB, 1, 2), dim3(256), lds, s>>>(p, g);
     };
     using std::integral_constant;
-    const int pr = shape->mfma_bf16;
+    const int pr = act16 ? 3 : shape->mfma_bf16;
     if (HL == 256) {
       if (pr == 0) launch_fh(integral_constant<int, 256>{}, integral_constant<int, 0>{});
       else if (pr == 1) launch_fh(integral_constant<int, 256>{}, integral_constant<int, 1>{});
+      else if (pr == 3) launch_fh(integral_constant<int, 256>{}, integral_constant<int, 3>{});
       else launch_fh(integral_constant<int, 256>{}, integral_constant<int, 2>{});
     } else {
       if (pr == 0) launch_fh(integral_constant<int, 128>{}, integral_constant<int, 0>{});
       else if (pr == 1) launch_fh(integral_constant<int, 128>{}, integral_constant<int, 1>{});
+      else if (pr == 3) launch_fh(integral_constant<int, 128>{}, integral_constant<int, 3>{});
       else launch_fh(integral_constant<int, 128>{}, integral_constant<int, 2>{});
     }
     catppo_plan_note(ctx, "last hidden layer + heads + PPO loss + head backward: fwd_head_kernel<%d, prec %d>, %d tiles x 2 networks "
@@ -760,6 +810,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       per = (int)cdiv64(M, splits);
       per = (per + gemm::BK - 1) / gemm::BK * gemm::BK;
     }
+    if (act16) per = (per + 31) / 32 * 32;            // 32-k slabs of the bf16-stored weight-gradient loop
     splits = (int)cdiv64(M, per);
     pw.splits = splits;
     pw.kc_per_split = per;
@@ -840,14 +891,16 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     // is the plain 64x64-tile fp32 launch on the caller's stream; CATPPO_DW0_FOLD=0 keeps GEMM and fold apart (A/B)
     static const int dw0_fold = env_int("CATPPO_DW0_FOLD", 1);
     const bool dw_with_fold = !pair && l == 0 && dw0_fold && !fork && !overlap && segs.n > 0 &&
-                              !(pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256);      // launch_gemm_auto's 128x128 rule
+                              (act16 || !(pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256));      // launch_gemm_auto's 128x128 rule
     if (dw_with_fold) {
       const int t64 = tiles_of<64, 64>(pw), n_gemm = t64 * pw.nets * pw.splits;
       constexpr size_t lds = gemm::smem_bytes<64, 64, false, false>();
       static_assert(lds >= 4096, "the fold workgroups use 1024 floats of the same allocation");
       const dim3 grid((unsigned)(n_gemm + kFoldX * segs.n));
       double* nslots = ne ? ne->part + ne->n_slots : (double*)nullptr;
-      if (bf16 == 2)
+      if (act16)
+        hipLaunchKernelGGL(dw_fold_kernel<5>, grid, dim3(256), lds, s, pw, segs, t64, n_gemm, hp->ent_coef, hp->vf_coef, nslots);
+      else if (bf16 == 2)
         hipLaunchKernelGGL(dw_fold_kernel<2>, grid, dim3(256), lds, s, pw, segs, t64, n_gemm, hp->ent_coef, hp->vf_coef, nslots);
       else if (bf16 == 1)
         hipLaunchKernelGGL(dw_fold_kernel<1>, grid, dim3(256), lds, s, pw, segs, t64, n_gemm, hp->ent_coef, hp->vf_coef, nslots);
@@ -871,7 +924,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         tail_forked = true;
       }
     } else if (!pair) {
-      launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
+      if (act16) launch_gemm_prec<64, 64, false, false, gemm::EPI_PARTIAL, 5>(pw, side);     // bf16-stored dZ_0, fp32 observations
+      else launch_gemm_auto<false, false, gemm::EPI_PARTIAL>(pw, side, bf16);
       catppo_plan_note(ctx, "layer %d weight gradient (%d x %d, %d splits of %d rows): gemm_f32_kernel, split-K partials "
                        "[own launch: first layer without the fold (precision %d / switches), or the side-stream experiment]",
                        l, out, in, splits, per, bf16);
@@ -897,7 +951,17 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         px.op[net].C = w.dZ[net][l - 1];
         px.op[net].aux = w.H[net][l - 1];
       }
-      if (pair) {
+      if (act16) {
+        // dZ_l (A) and the transposed bf16 weight copy (B, [in][out]) are K-contiguous: contraction sizes in FLOAT units;
+        // aux (H_{l-1}) and the output dZ_{l-1} are bf16-stored: ldaux / ldc in bf16 elements
+        px.Kc = out / 2, px.lda = out / 2, px.ldb = out / 2;
+        for (int net = 0; net < 2; ++net) px.op[net].B = reinterpret_cast<const float*>(w.w16t + L.off_w[net][l]);
+      }
+      if (pair && act16) {
+        launch_dw_dx_pair16(pw, px, s, ctx->n_cu);
+        catppo_plan_note(ctx, "layer %d weight gradient (%d x %d, %d splits of %d rows) + data gradient (%lld x %d, k = %d): "
+                         "gemm_pair_kernel on bf16-stored operands, ONE launch", l, out, in, splits, per, (long long)M, in, out);
+      } else if (pair) {
         launch_dw_dx_pair(pw, px, s, bf16, ctx->n_cu);
         catppo_plan_note(ctx, "layer %d weight gradient (%d x %d, %d splits of %d rows) + data gradient (%lld x %d, k = %d): "
                          "gemm_pair_kernel, ONE launch%s", l, out, in, splits, per, (long long)M, in, out,

@@ -66,6 +66,8 @@ struct MlpWs {
   float* head_w;           // [nb_head][(A+1)*HL]
   float* head_s;           // [nb_head][kHeadScalars]
   double* norm_part;       // [kNormSlots]: squared-norm partials emitted by the launches that fold the gradient (NormEmit)
+  uint16_t* w16;           // [n_flat] bf16 copy of the flat parameters (hidden layers >= 1), bf16-stored mode ("act16", gemm_f32.h)
+  uint16_t* w16t;          // [n_flat] the same matrices transposed ([in][out]): K-contiguous operand of the data gradient
   uint64_t bytes;
 };
 constexpr int kHeadDiag = 8;
@@ -119,6 +121,10 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
     w->head_s = (float*)take(sizeof(float) * nbh * head_scalars(A));
   }
   w->norm_part = (double*)take(sizeof(double) * kNormSlots);
+  if (training && s->mfma_bf16 == 1) {
+    w->w16 = (uint16_t*)take(sizeof(uint16_t) * L.n_flat);
+    w->w16t = (uint16_t*)take(sizeof(uint16_t) * L.n_flat);
+  }
   w->bytes = used;
   return ok;
 }
@@ -216,6 +222,36 @@ void launch_gemm_auto(const Params& p, hipStream_t s, int prec) {
 
 template <int BM, int BN>
 constexpr int tiles_of(const Params& p) { return ((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM); }
+
+// one operand-precision mode, explicitly (the bf16-stored modes 3 / 4 of gemm_f32.h)
+template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int PREC>
+void launch_gemm_prec(const Params& p, hipStream_t s) {
+  dim3 grid(tiles_of<BM, BN>(p), 1, p.nets * p.splits);
+  constexpr size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
+  gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, PREC><<<grid, dim3(256), lds, s>>>(p);
+}
+
+// bf16-stored mode: weight gradient (both operands bf16-stored, IILoop16) + data gradient against the TRANSPOSED bf16 weight
+// copy (K-contiguous x K-contiguous) in one launch; tile rules of launch_dw_dx_pair
+template <int BM0, int BN0, int BM1, int BN1>
+void launch_pair_tiles16(const Params& pw, const Params& px, hipStream_t s) {
+  const int t0 = tiles_of<BM0, BN0>(pw), n0 = t0 * pw.nets * pw.splits;
+  const int t1 = tiles_of<BM1, BN1>(px), n1 = t1 * px.nets * px.splits;
+  constexpr size_t lds0 = gemm::smem_bytes<BM0, BN0, false, false>();
+  constexpr size_t lds1 = gemm::smem_bytes<BM1, BN1, true, true>();
+  constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
+  gemm::gemm_pair_kernel<BM0, BN0, false, false, gemm::EPI_PARTIAL, BM1, BN1, true, true, gemm::EPI_MUL_DELU, 3>
+      <<<dim3(n0 + n1), dim3(256), lds, s>>>(pw, px, t0, n0, t1);
+}
+void launch_dw_dx_pair16(const Params& pw, const Params& px, hipStream_t s, int n_cu) {
+  const bool underfilled = tiles_of<128, 128>(pw) * pw.nets * pw.splits < n_cu;
+  const bool big = pw.I >= 128 && pw.J >= 128 && pw.kc_per_split >= 256 && !underfilled;
+  const bool wide = px.J >= 128;
+  if (big && wide) launch_pair_tiles16<128, 128, 64, 128>(pw, px, s);
+  else if (big) launch_pair_tiles16<128, 128, 64, 64>(pw, px, s);
+  else if (wide) launch_pair_tiles16<64, 64, 64, 128>(pw, px, s);
+  else launch_pair_tiles16<64, 64, 64, 64>(pw, px, s);
+}
 
 // weight gradient (problem 0: 128x128 tiles when the layer allows, else 64x64) + data gradient (problem 1: 64x128
 // tiles - measured best inside the pair on MI355X, 350 -> 338 us per minibatch against 64x64 - or 64x64 for
@@ -333,6 +369,14 @@ __device__ __forceinline__ void store_vec_wt(float* p, const float (&v)[CPL]) {
       asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(dst), "v"(o) : "memory");
     }
   }
+}
+
+// 8 consecutive values as bf16 (RNE), one 16-byte write-through store (bf16-stored activations, gemm_f32.h "act16")
+__device__ __forceinline__ void store8_bf16_wt(uint16_t* p, const float (&v)[8]) {
+  gemm::u32x4 pk;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pk[j] = gemm::pk_bf16(v[2 * j], v[2 * j + 1]);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(pk) : "memory");
 }
 
 template <int CPL>

@@ -555,7 +555,28 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
     }
     FH_TL(4);
     // B + stream-out: dZ[r][c] = fl(G[r] w[c]) * elu'(H[r][c]); a wave writes whole rows (1 KB / 512 B contiguous)
-    {
+    if constexpr (PREC == 3) {                   // bf16-stored dZ: 8 columns per lane
+      constexpr int C8 = HL / 8;
+      constexpr int RPP = 256 / C8;
+      const int c8 = tid % C8, r_in = tid / C8;
+      float wv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) wv[e] = sW[8 * c8 + e];
+#pragma unroll 4
+      for (int rb = 0; rb < BM; rb += RPP) {
+        const int r = rb + r_in;
+        if (r < rows) {
+          const float gr = sG[r * 16];
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float hv = Hs[r * LD + 8 * c8 + e];
+            o[e] = __builtin_fmaf(gr, wv[e], 0.0f) * (hv > 0.0f ? 1.0f : hv + 1.0f);
+          }
+          store8_bf16_wt(reinterpret_cast<uint16_t*>(g.dZc) + (i0 + r) * HL + 8 * c8, o);
+        }
+      }
+    } else {
       constexpr int C4 = HL / 4;                 // float4 chunks per row
       constexpr int RPP = 256 / C4;              // rows per pass of the workgroup
       const int c4 = tid % C4, r_in = tid / C4;
@@ -826,7 +847,22 @@ __global__ __launch_bounds__(256, 2) void fwd_head_kernel(const Params p, const 
   // barrier between its in-place writes and these reads)
   __builtin_amdgcn_wave_barrier();
   FH_TL(5);
-  {
+  if constexpr (PREC == 3) {                   // bf16-stored dZ: 8 columns per lane
+    constexpr int C8 = HL / 16;                // 8-column chunks per region row
+    constexpr int RPI = 64 / C8;
+    const int c8 = lane % C8, r_in = lane / C8;
+    uint16_t* dZ = reinterpret_cast<uint16_t*>(net == 1 ? g.dZa : g.dZc);
+#pragma unroll 4
+    for (int rb = 0; rb < 32; rb += RPI) {
+      const int r = 32 * wm + rb + r_in;
+      if (r < rows) {
+        const float4 v0 = *reinterpret_cast<const float4*>(Hs + r * LD + wn * (HL / 2) + 8 * c8);
+        const float4 v1 = *reinterpret_cast<const float4*>(Hs + r * LD + wn * (HL / 2) + 8 * c8 + 4);
+        const float o[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        store8_bf16_wt(dZ + (i0 + r) * HL + wn * (HL / 2) + 8 * c8, o);
+      }
+    }
+  } else {
     constexpr int C4 = HL / 8;                 // float4 chunks per region row
     constexpr int RPI = 64 / C4;               // region rows per store instruction
     const int c4 = lane % C4, r_in = lane / C4;

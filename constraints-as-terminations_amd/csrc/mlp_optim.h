@@ -160,3 +160,26 @@ __global__ __launch_bounds__(256) void clip_adam_dev_kernel(float* __restrict__ 
   const AdamCoef c{s_coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, step_size, bc2_sqrt};
   adam_all(p, g, m, v, n, c);
 }
+
+// ------------------------------------------------------------------------------- bf16 weight copies (bf16-stored mode)
+// W_l (l >= 1) of both networks as bf16, as stored ([out][in]: forward operand) and transposed ([in][out]: the data gradient's
+// K-contiguous operand), once per optimiser step from the fp32 master parameters - 0.26 M elements at cfg5.
+struct W16Segs {
+  int n;
+  int64_t off[2 * CATPPO_MAX_HIDDEN];
+  int out[2 * CATPPO_MAX_HIDDEN], in[2 * CATPPO_MAX_HIDDEN];
+  int64_t first[2 * CATPPO_MAX_HIDDEN + 1];
+};
+__global__ __launch_bounds__(256) void w16_convert_kernel(const float* __restrict__ params, uint16_t* __restrict__ w16,
+                                                          uint16_t* __restrict__ w16t, const W16Segs t) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= t.first[t.n]) return;
+  int i = 0;
+  while (i + 1 < t.n && e >= t.first[i + 1]) ++i;
+  const int64_t le = e - t.first[i];
+  const int r = (int)(le / t.in[i]), c = (int)(le % t.in[i]);
+  const __bf16 b = (__bf16)params[t.off[i] + le];
+  const uint16_t bits = __builtin_bit_cast(uint16_t, b);
+  w16[t.off[i] + le] = bits;
+  w16t[t.off[i] + (int64_t)c * t.out[i] + r] = bits;
+}

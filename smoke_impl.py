@@ -122,19 +122,23 @@ def branch_flip_report(trainer, orc, tight_bar):
     assert trainer.param_trace.shape[0] == n, (trainer.param_trace.shape, n)
     errs = [float((logical_params(agent, trainer.param_trace[k]).double() - steps[k]["params"].double()).abs().max())
             for k in range(n)]
-    bad = [k for k in range(n) if errs[k] >= tight_bar]
-    if not bad:
+    k = first_parting_step(errs, tight_bar)
+    if k is None:
         return dict(first_step=None, errs=errs)
-    k = bad[0]
-    # the step the trajectories PART at is where the distance jumps (cfg4: 4.5e-8 for nine steps, then 1e-5 .. 2e-5 in one
-    # step - which may or may not already be above the bar), not the first one above an absolute threshold
-    for j in range(1, k + 1):
-        if errs[j] >= 1e-6 and errs[j] >= 30.0 * max(errs[:j]):
-            k = j
-            break
     theta = trainer.param_trace[k - 1] if k > 0 else trainer.param_trace_start
-    mb = steps[k]["mb"].to(trainer.device)
+    codes, ratio_d, dl_d = device_branches(trainer, theta, steps[k]["mb"].to(trainer.device))
+    rep = analyse_branches(codes, ratio_d, dl_d, steps[k], float(cfg.clip_coef), bool(cfg.clip_vloss))
+    return dict(first_step=k, n_steps=n, err_before=errs[k - 1] if k > 0 else 0.0, err_at=errs[k], errs=errs, **rep)
+
+
+def device_branches(trainer, theta, mb, adv_stats=None):
+    """The clip branch every sample of minibatch `mb` (row indices into the update phase's batch, trainer.trace_batch) takes
+    in the TRAINING kernels under the flat parameters `theta` (catppo_debug_clip_branches: the loss kernel exports them - not
+    a re-derivation, the head sums of the rollout kernel differ by ~1e-7), and the per-sample quantities they were decided
+    on as catppo_policy_step sees them: (codes [2 M] long, ratio [M], newvalue_n - old value_n [M]), on the host."""
+    agent, nat = trainer.agent, trainer.nat
     tb = trainer.trace_batch                      # the update phase's own inputs (snapshot taken when it started)
+    mb = mb.contiguous()
     x = tb["obs"][mb].float().contiguous()
     act = tb["actions"][mb].float().contiguous()
     M = int(mb.numel())
@@ -142,34 +146,40 @@ def branch_flip_report(trainer, orc, tight_bar):
     nat.mlp_reserve(agent.shape, M)
     nat.policy_act(agent.shape, theta.contiguous(), x, M, None, a_out, lp, val, given_action=act)
     torch.cuda.synchronize()
-    clip = float(cfg.clip_coef)
     ratio_d = (lp - tb["logprobs"][mb].float()).exp().cpu()
     nv_d = ((val - agent.value_rms.running_mean) / torch.sqrt(agent.value_rms.running_var + 1e-8)).cpu()
     dl_d = nv_d - tb["values_n"][mb].float().cpu()
-    ratio_o, dl_o = steps[k]["ratio"], steps[k]["newvalue_n"] - steps[k]["old_values_n"]
-
-    def code(v, centre):
-        return (v < centre - clip).long() + 2 * (v > centre + clip).long()
-    # the branches the TRAINING kernels take (not a re-derivation: the head sums of the rollout kernel differ by ~1e-7)
     codes = torch.full((2 * M,), -1, dtype=torch.int32, device=trainer.device)
     g_s, d_s = torch.zeros_like(trainer.grad), torch.zeros_like(trainer.diag)
     nat.debug_clip_branches(codes)
     try:
         nat.ppo_minibatch_grad(agent.shape, trainer.hp, theta.contiguous(), tb["obs"].float(), tb["actions"].float(),
                                tb["logprobs"].float(), tb["advantages"].float(), tb["returns_n"].float(), tb["values_n"].float(),
-                               mb.contiguous(), agent.value_rms.running_mean, agent.value_rms.running_var, None, g_s, d_s)
+                               mb, agent.value_rms.running_mean, agent.value_rms.running_var, adv_stats, g_s, d_s)
         torch.cuda.synchronize()
     finally:
         nat.debug_clip_branches(None)
     codes = codes.cpu().long()
     assert int(codes.min()) >= 0, "the loss kernel did not export its clip branches"
+    return codes, ratio_d, dl_d
+
+
+def analyse_branches(codes, ratio_d, dl_d, step, clip, clip_vloss):
+    """device clip branches (device_branches) of one optimiser step against the oracle's record of the same step
+    (PPOOracle.step_trace entry): which samples sit on different sides of a clip boundary, how close the oracle has them to
+    it, how far device and oracle are apart in the per-sample quantities themselves."""
+    M = int(ratio_d.numel())
+    ratio_o, dl_o = step["ratio"], step["newvalue_n"] - step["old_values_n"]
+
+    def code(v, centre):
+        return (v < centre - clip).long() + 2 * (v > centre + clip).long()
     pg_diff = codes[:M] != code(ratio_o, 1.0)
     m_pg = ((ratio_o - 1.0).abs() - clip).abs()
-    if bool(cfg.clip_vloss):
+    if clip_vloss:
         # two surfaces: the clip range of (newvalue - old value), and - outside it - which of (unclipped, clipped) is the max
         v_diff = (codes[M:] & 3) != code(dl_o, 0.0)
-        e1 = steps[k]["newvalue_n"] - steps[k]["returns_n"]
-        e2 = steps[k]["old_values_n"] + dl_o.clamp(-clip, clip) - steps[k]["returns_n"]
+        e1 = step["newvalue_n"] - step["returns_n"]
+        e2 = step["old_values_n"] + dl_o.clamp(-clip, clip) - step["returns_n"]
         vl1, vl2 = e1 * e1, e2 * e2
         max_o = (vl1 > vl2).long() + 2 * (vl1 < vl2).long()
         vmax_diff = ((codes[M:] >> 2) != max_o) & ~v_diff & (code(dl_o, 0.0) != 0)
@@ -179,11 +189,25 @@ def branch_flip_report(trainer, orc, tight_bar):
         m_v = m_vmax = torch.zeros_like(m_pg)
     margins = torch.cat([m_pg[pg_diff], m_v[v_diff], m_vmax[vmax_diff]])
     v_diff = v_diff | vmax_diff
-    return dict(first_step=k, n_steps=n, err_before=errs[k - 1] if k > 0 else 0.0, err_at=errs[k], errs=errs,
-                flipped_surrogate=int(pg_diff.sum()), flipped_value=int(v_diff.sum()), flipped_value_max_branch=int(vmax_diff.sum()),
+    return dict(flipped_surrogate=int(pg_diff.sum()), flipped_value=int(v_diff.sum()), flipped_value_max_branch=int(vmax_diff.sum()),
                 max_margin_of_flipped=float(margins.max()) if margins.numel() else None,
                 max_device_oracle_ratio_diff=float((ratio_d - ratio_o).abs().max()),
                 max_device_oracle_value_diff=float((dl_d - dl_o).abs().max()))
+
+
+def first_parting_step(errs, tight_bar):
+    """the optimiser step two parameter trajectories PART at: where their distance jumps off its rounding-level plateau, not
+    the first step above an absolute threshold.  cfg4: 4.5e-8 for nine steps, then 1e-5 .. 2e-5 in ONE step; two ranks at
+    cfg3's per-rank shape: 7.7e-8 .. 1.2e-7 for 85 steps, then 8.7e-7 and +0.7e-6 per step from there on (Adam's momentum
+    carries the flipped sample's gradient share) - the tight bar is crossed eight steps AFTER the step that explains it."""
+    bad = [k for k in range(len(errs)) if errs[k] >= tight_bar]
+    if not bad:
+        return None
+    k = bad[0]
+    for j in range(1, k + 1):
+        if errs[j] >= 4e-7 and errs[j] >= 4.0 * max(errs[:j]):
+            return j
+    return k
 
 
 def compare(trainer, orc, out, tol_scale=1.0, check=True):

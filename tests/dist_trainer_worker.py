@@ -66,6 +66,8 @@ def _rank_body(rank, world, out_dir, spec):
     torch.manual_seed(seed + 1000 * rank)        # different initialisations: rank 0's must win (parameter broadcast)
     tr = PPOTrainer(env, agent_cfg)
     assert tr.world == world and tr.rank == rank and tr.n_envs_global == float(spec["n_total"])
+    if spec.get("trace"):      # parameters after every optimiser step of the LAST iteration (branch analysis below)
+        tr.trace_params = True
     init_sd = {k: v.detach().cpu().numpy().copy() for k, v in tr.agent.state_dict().items()}
     A, B = tr.A, T * N
     rs_eps = np.random.RandomState(seed)                      # the UNION's noise; every rank takes its env columns
@@ -96,6 +98,27 @@ def _rank_body(rank, world, out_dir, spec):
         loss=np.asarray([s["mean_pg_loss"] for s in stats] + [s["mean_v_loss"] for s in stats]),
         ep_sums=np.stack([f(cm._episode_sums[n]) for n in cm.active_terms]),
         ep_means=np.stack([f(cm._cstr_mean_values[n]) for n in cm.active_terms]))
+    if spec.get("trace"):
+        # Per optimiser step of the last iteration: this rank's rows of the global minibatch re-evaluated under the parameters
+        # BEFORE the step with the loss kernel's clip-branch export on (smoke_impl.device_branches) - what the parent compares
+        # with the oracle's branches when the parameter trajectories part; rank 0 also hands over the parameters after every step.
+        n_steps, M_r = tr.param_trace.shape[0], int(tr.M)
+        codes = np.zeros((n_steps, 2, M_r), np.int8)
+        ratio, dl = np.zeros((n_steps, M_r), np.float32), np.zeros((n_steps, M_r), np.float32)
+        perms_last = torch.from_numpy(perms_used[-1]).cuda()
+        for k in range(n_steps):
+            e, j = divmod(k, int(tr.n_mb))
+            m = int(tr._mb_rows[j])
+            mb = perms_last[e][j * M_r:j * M_r + m]
+            theta = tr.param_trace[k - 1] if k > 0 else tr.param_trace_start
+            stats_k = tr._adv_stats_all[k] if getattr(tr, "_adv_stats_all", None) is not None and tr.hp.adv_stats_external else None
+            c, r_d, d_d = smoke_impl.device_branches(tr, theta, mb, adv_stats=stats_k)
+            codes[k, 0, :m], codes[k, 1, :m] = c[:m].numpy(), c[m:].numpy()
+            ratio[k, :m], dl[k, :m] = r_d.numpy(), d_d.numpy()
+        out["trace/codes"], out["trace/ratio"], out["trace/dl"] = codes, ratio, dl
+        if rank == 0:
+            out["trace/params"] = np.stack([smoke_impl.logical_params(tr.agent, tr.param_trace[k]).cpu().numpy()
+                                            for k in range(n_steps)])
     for k, v in init_sd.items():
         out["init/" + k] = v
     sd = tr.agent.state_dict()
@@ -142,6 +165,7 @@ def union_oracle(spec, world, ranks, proto_env):
                                rollout_dtype=str(over.get("rollout_dtype", "fp32")))
     rs_eps = np.random.RandomState(spec["seed"])
     out = None
+    orc.trace = bool(spec.get("trace"))          # step_trace of the last iteration (PPOOracle resets it per iteration)
     for it in range(spec["iters"]):
         eps = rs_eps.standard_normal((T, n_tot, 12)).astype(np.float32)
         acts = torch.from_numpy(np.concatenate([r["actions"][it] for r in ranks], axis=1))

@@ -148,3 +148,47 @@ def test_bf16_training_iterations_run_and_stay_close_to_fp32():
     step = np.abs(p_32 - p0).max()
     assert step > 1e-4                                   # the optimiser moved
     assert np.abs(p_bf - p_32).max() < 0.5 * step + 1e-3, (np.abs(p_bf - p_32).max(), step)
+
+
+def _grad_in_process(tmp_path, tag, D, A, hidden, Bsz, M, **env_over):
+    """one minibatch gradient of the bf16-operand mode in a fresh process (the switches are read once per process)"""
+    import os
+    import subprocess
+    import sys
+    import test_gpu_kernels as TK
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / f"{tag}.npz")
+    code = TK._FUSED_VS_SPLIT.format(root=root, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=1, out=out)
+    code = code.replace("nat.mlp_reserve(shape, M)", "nat.mlp_reserve(shape, M); nat.plan_log(1)")
+    code = code.replace("np.savez(", "open({!r}, 'w').write(nat.plan_log(-1)); np.savez(".format(out + ".plan"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_over), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out), open(out + ".plan").read()
+
+
+@pytest.mark.parametrize("D,A,hidden,Bsz,M", [
+    (48, 12, (256, 256, 256), 16384, 16384),      # BASELINE configs[4]'s minibatch
+    (45, 12, (512, 256, 128), 8192, 4133),        # reference shapes, ragged rows (last tile 37 rows, last split short)
+    (235, 12, (256, 256, 256), 8192, 4096),       # wide first layer (cfg4's observations): first-layer dW on 64x64 tiles
+])
+def test_bf16_stored_activations_equal_the_fp32_stored_path(tmp_path, D, A, hidden, Bsz, M):
+    """Round 6 ("act16", gemm_f32.h): hidden activations and dZ STORED as bf16 + bf16 weight copies, against the same mode
+    with fp32-stored tensors rounded where a GEMM consumes them (rounds 2-5).  The GEMM operands are the same bf16 values
+    either way and every instruction contracts the same 16 k, but a k sits in another operand slot of the instruction (k = 8 h
+    + e here, 8 (i / 4) + 4 h + i % 4 there) and the matrix unit's internal summation order follows the slots: the FORWARD -
+    every diagnostic of the loss - agrees to fp32 rounding (recorded: 1.2e-7 relative), not bit for bit.  The backward differs
+    where the rounded tensors are used outside a GEMM: elu'(H) = H + 1 of a negative activation (2^-9 relative) and the bias
+    gradients' column sums of dZ."""
+    import parity_record
+    new, plan_new = _grad_in_process(tmp_path, "act16", D, A, hidden, Bsz, M, CATPPO_ACT16="1")
+    old, plan_old = _grad_in_process(tmp_path, "act32", D, A, hidden, Bsz, M, CATPPO_ACT16="0")
+    assert "bf16-stored" in plan_new and "w16_convert_kernel" in plan_new and "bf16-stored" not in plan_old, plan_new
+    np.testing.assert_allclose(new["diag"][:7], old["diag"][:7], rtol=1e-6, atol=0)
+    g1, g0 = new["grad"].astype(np.float64), old["grad"].astype(np.float64)
+    assert np.isfinite(g1).all() and np.abs(g0).max() > 0
+    scale = np.abs(g0).max()
+    rec = {"max_rel_to_largest": float(np.abs(g1 - g0).max() / scale),
+           "mean_abs_rel_to_mean_abs": float(np.abs(g1 - g0).mean() / np.abs(g0).mean())}
+    parity_record.record(f"act16_vs_fp32_stored_{D}_{'x'.join(map(str, hidden))}_{M}", rec, sizes=dict(D=D, hidden=list(hidden), M=M), seed=6)
+    print(rec)
+    assert rec["max_rel_to_largest"] < 4e-3 and rec["mean_abs_rel_to_mean_abs"] < 2e-2, rec
