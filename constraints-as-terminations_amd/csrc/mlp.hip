@@ -594,7 +594,6 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
           tot += (int64_t)shape->hidden[l] * L.in_dim[l];
         }
       ws16.first[ws16.n] = tot;
-      hipLaunchKernelGGL(w16_convert_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, params, w.w16, w.w16t, ws16);
       for (int l = 0; l < nl - 1; ++l) {
         Params pf{};
         pf.xcd_legacy = xcd_legacy();
@@ -613,15 +612,19 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         }
         if (l == 0) {                                        // fp32-stored operands (observations, W_0), bf16-stored output
           pf.Kc = L.in_dim[0], pf.lda = L.in_dim[0], pf.ldb = L.in_dim[0];
-          launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 4>(pf, s);
+          const int n_conv = (int)((cdiv64(tot, 256) + 7) / 8 * 8), t0 = tiles_of<64, 64>(pf);
+          constexpr size_t lds0 = gemm::smem_bytes<64, 64, true, true>();
+          hipLaunchKernelGGL(fwd0_w16_kernel, dim3((unsigned)(n_conv + t0 * 2)), dim3(256), lds0, s, pf, n_conv, t0, params, w.w16,
+                             w.w16t, ws16);
         } else {                                             // bf16-stored operands: contraction sizes in FLOAT units
           pf.Kc = L.in_dim[l] / 2, pf.lda = L.in_dim[l] / 2, pf.ldb = L.in_dim[l] / 2;
           if (pf.J >= 128 && L.in_dim[l] >= 256) launch_gemm_prec<128, 128, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
           else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
         }
       }
-      catppo_plan_note(ctx, "minibatch %lld rows, bf16-stored activations: w16_convert_kernel (%lld weights as bf16, stored + "
-                       "transposed) + %d layer-wise forward GEMM launches writing bf16", (long long)M, (long long)tot, nl - 1);
+      catppo_plan_note(ctx, "minibatch %lld rows, bf16-stored activations: fwd0_w16_kernel (layer 0 + %lld weights as bf16, stored + "
+                       "transposed, in one launch) + %d layer-wise forward GEMM launch(es) on bf16-stored operands", (long long)M,
+                       (long long)tot, nl - 2);
     } else if (rows_fwd_env && M >= rows_fwd_min && M <= (1 << 20) && nl - 1 <= 3 &&
         rows_fwd_plan(shape, L, nl - 1, 64, &ra, &rlds)) {
       ra.x = w.xmb, ra.params = params, ra.M = M, ra.net0 = 0, ra.do_head = 0;

@@ -170,16 +170,31 @@ struct W16Segs {
   int out[2 * CATPPO_MAX_HIDDEN], in[2 * CATPPO_MAX_HIDDEN];
   int64_t first[2 * CATPPO_MAX_HIDDEN + 1];
 };
-__global__ __launch_bounds__(256) void w16_convert_kernel(const float* __restrict__ params, uint16_t* __restrict__ w16,
-                                                          uint16_t* __restrict__ w16t, const W16Segs t) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void w16_convert_block(const float* __restrict__ params, uint16_t* __restrict__ w16,
+                                                  uint16_t* __restrict__ w16t, const W16Segs& t, const int block) {
+  const int64_t e = (int64_t)block * 256 + threadIdx.x;
   if (e >= t.first[t.n]) return;
   int i = 0;
   while (i + 1 < t.n && e >= t.first[i + 1]) ++i;
   const int64_t le = e - t.first[i];
-  const int r = (int)(le / t.in[i]), c = (int)(le % t.in[i]);
-  const __bf16 b = (__bf16)params[t.off[i] + le];
-  const uint16_t bits = __builtin_bit_cast(uint16_t, b);
-  w16[t.off[i] + le] = bits;
-  w16t[t.off[i] + (int64_t)c * t.out[i] + r] = bits;
+  w16[t.off[i] + le] = __builtin_bit_cast(uint16_t, (__bf16)params[t.off[i] + le]);
+  // transposed copy: consecutive threads WRITE consecutive elements ([in][out], r fastest) and read a column of W from L2
+  const int c = (int)(le / t.out[i]), r = (int)(le % t.out[i]);
+  w16t[t.off[i] + le] = __builtin_bit_cast(uint16_t, (__bf16)params[t.off[i] + (int64_t)r * t.in[i] + c]);
+}
+
+// The first layer's forward (fp32-stored observations and W_0, bf16-stored output: PREC 4) with the weight conversion riding in
+// the same launch: workgroups [0, n_conv) convert (n_conv a multiple of 8: the XCD of a GEMM workgroup is that of its tile index),
+// the rest run 64x64 tiles.  Nothing in this launch reads the copies; the next launch (layer 1) does.
+__global__ __launch_bounds__(256) void fwd0_w16_kernel(const gemm::Params p, const int n_conv, const int tiles,
+                                                       const float* __restrict__ params, uint16_t* __restrict__ w16,
+                                                       uint16_t* __restrict__ w16t, const W16Segs t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < n_conv) {
+    w16_convert_block(params, w16, w16t, t, b);
+    return;
+  }
+  const gemm::TileId id = gemm::xcd_tile_of(b - n_conv, tiles, (gridDim.x - n_conv) / tiles, p.xcd_legacy);
+  gemm::gemm_body<64, 64, true, true, gemm::EPI_BIAS_ELU, gemm::BK, 4>(p, id.tile, id.bz, smem);
 }

@@ -182,7 +182,7 @@ def test_bf16_stored_activations_equal_the_fp32_stored_path(tmp_path, D, A, hidd
     import parity_record
     new, plan_new = _grad_in_process(tmp_path, "act16", D, A, hidden, Bsz, M, CATPPO_ACT16="1")
     old, plan_old = _grad_in_process(tmp_path, "act32", D, A, hidden, Bsz, M, CATPPO_ACT16="0")
-    assert "bf16-stored" in plan_new and "w16_convert_kernel" in plan_new and "bf16-stored" not in plan_old, plan_new
+    assert "bf16-stored" in plan_new and "fwd0_w16_kernel" in plan_new and "bf16-stored" not in plan_old, plan_new
     np.testing.assert_allclose(new["diag"][:7], old["diag"][:7], rtol=1e-6, atol=0)
     g1, g0 = new["grad"].astype(np.float64), old["grad"].astype(np.float64)
     assert np.isfinite(g1).all() and np.abs(g0).max() > 0

@@ -723,7 +723,9 @@ def test_fused_head_launch_equals_the_two_launch_path(tmp_path, D, A, hidden, Bs
     for flag in ("1", "0"):
         out = str(tmp_path / f"fused{flag}.npz")
         code = _FUSED_VS_SPLIT.format(root=root, D=D, A=A, hidden=hidden, Bsz=Bsz, M=M, prec=prec, out=out)
-        env = dict(os.environ, CATPPO_FUSED_HEAD=flag)
+        # (bf16 operands: fp32-STORED activations on both sides - what the bf16-stored mode changes in the backward has its own
+        # test, tests/test_gpu_bf16.py::test_bf16_stored_activations_equal_the_fp32_stored_path)
+        env = dict(os.environ, CATPPO_FUSED_HEAD=flag, CATPPO_ACT16="0")
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(np.load(out))
