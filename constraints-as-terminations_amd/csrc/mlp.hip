@@ -619,7 +619,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
         } else {                                             // bf16-stored operands: contraction sizes in FLOAT units
           pf.Kc = L.in_dim[l] / 2, pf.lda = L.in_dim[l] / 2, pf.ldb = L.in_dim[l] / 2;
           if (pf.J >= 128 && L.in_dim[l] >= 256) launch_gemm_prec<128, 128, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
-          else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
+          else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);      // (64x64 for a wide layer: measured 0.8 us slower)
         }
       }
       catppo_plan_note(ctx, "minibatch %lld rows, bf16-stored activations: fwd0_w16_kernel (layer 0 + %lld weights as bf16, stored + "
@@ -901,6 +901,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       static_assert(lds >= 4096, "the fold workgroups use 1024 floats of the same allocation");
       const dim3 grid((unsigned)(n_gemm + kFoldX * segs.n));
       double* nslots = ne ? ne->part + ne->n_slots : (double*)nullptr;
+      // (round 6, again: 128x64 tiles for this GEMM - two accumulators per wave, the observations read once per 128 rows, partials
+      //  through the staged 16-byte stores round 4 did not have - measured 3 us per step SLOWER at cfg2 and at the reference shapes)
       if (act16)
         hipLaunchKernelGGL(dw_fold_kernel<5>, grid, dim3(256), lds, s, pw, segs, t64, n_gemm, hp->ent_coef, hp->vf_coef, nslots);
       else if (bf16 == 2)

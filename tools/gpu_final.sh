@@ -24,10 +24,12 @@ SQ_PASSES=0 bash tools/profile_bench.sh cfg5 $TAG >> "$OUT/final_profile.log" 2>
 # round 6: one rank's share of cfg3 at 8 ranks (2048-row minibatches: step16_kernel + dw_multi_kernel + fold), with the SQ passes
 bash tools/profile_bench.sh cfg3_shard $TAG >> "$OUT/final_profile.log" 2>&1
 python tools/pmc_sq_summary.py "$OUT/${TAG}_pmc_sq1_cfg3_shard.csv" "$OUT/${TAG}_pmc_sq2_cfg3_shard.csv" > "$OUT/${TAG}_pmc_sq_summary_cfg3_shard.json" 2>/dev/null
-cp "$OUT/${TAG}_pmc_traffic_cfg3_shard.json" "$OUT/${TAG}_bench_cfg3_shard_kernel_stats.csv" profiles/ 2>/dev/null
+# the bench lines below look the PMC summaries up under profiles/ (stamped with a hash of csrc/): put this call's there first
 mkdir -p profiles && cp "$OUT/${TAG}_pmc_traffic_cfg2.json" "$OUT/${TAG}_bench_cfg2_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg2_bf16x3.json" \
-   "$OUT/${TAG}_bench_cfg2_bf16x3_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg5.json" "$OUT/${TAG}_bench_cfg5_kernel_stats.csv" profiles/ 2>/dev/null
+   "$OUT/${TAG}_bench_cfg2_bf16x3_kernel_stats.csv" "$OUT/${TAG}_pmc_traffic_cfg5.json" "$OUT/${TAG}_bench_cfg5_kernel_stats.csv" \
+   "$OUT/${TAG}_pmc_traffic_cfg3_shard.json" "$OUT/${TAG}_bench_cfg3_shard_kernel_stats.csv" profiles/ 2>/dev/null
 bash tools/gpu_trace_one.sh reference $TAG > /dev/null 2>&1
+python tools/explain_plan.py --all > "$OUT/${TAG}_explain_plan.txt" 2>/dev/null
 echo "== bench lines ($(( $(date +%s) - T0 )) s)"
 timeout 400 python bench.py 2> "$OUT/${TAG}_bench_cfg2.err" | tail -1 > "$OUT/${TAG}_bench_cfg2.json"
 B="timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline"
