@@ -343,7 +343,8 @@ struct PkLoop {
 //       split-bf16 loop (PkLoop) reads: fragment = four ds_read_b32.  B may be an fp32 matrix (the observations of the first
 //       layer: PREC 5): float4 of four rows at k, k + 1, packed.
 // PREC:  3 = both operands bf16-stored (outputs / aux bf16 too: EPI_BIAS_ELU, EPI_MUL_DELU)   4 = fp32-stored operands rounded at
-//        use (PREC 1's loop) with a bf16-stored OUTPUT (first layer forward)   5 = weight gradient with an fp32-stored B.
+//        use (PREC 1's loop) with a bf16-stored OUTPUT (first layer forward)   5 = weight gradient with an fp32-stored B
+//        6 = 3 with an fp32-stored output (last hidden layer of a rollout forward: the head kernel reads fp32).
 template <int BM, int BN, int EPI, bool B16, int WAVES_M>
 struct IILoop16 {
   static constexpr int WAVES_N = 4 / WAVES_M;
@@ -646,7 +647,7 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   constexpr bool kPacked = PREC == 2 && GEMM_PACKED && BK == 16 && (A_KC || BM >= 128) && (B_KC || BN >= 128);
   // bf16-STORED operands (act16, see IILoop16): the weight-gradient loop of its own / the K-contiguous loop on reinterpreted slabs
   constexpr bool kSrc16II = (PREC == 3 || PREC == 5) && !A_KC && !B_KC;
-  constexpr bool kSrc16KK = PREC == 3 && A_KC && B_KC;
+  constexpr bool kSrc16KK = (PREC == 3 || PREC == 6) && A_KC && B_KC;
   static_assert(PREC <= 2 || PREC == 4 || kSrc16II || kSrc16KK, "operand layouts of the bf16-stored modes");
   static_assert(PREC <= 2 || BK == 16, "bf16-stored modes: 16-float (32-k) slabs");
   constexpr bool OUT16 = (PREC == 3 || PREC == 4) && (EPI == EPI_BIAS_ELU || EPI == EPI_MUL_DELU);     // C (and aux) stored as bf16

@@ -368,7 +368,13 @@ int policy_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const float* par
       return CATPPO_OK;
     }
   }
-  forward_hidden(shape, L, params, x, N, w, 0, critic_only ? 1 : 2, s);
+  // bf16 operands, large batches (BASELINE configs[4]: 32768 envs): bf16-stored activations between the layer-wise launches
+  // (round 6, gemm_f32.h "act16"); the last hidden layer writes fp32 for head_act_kernel.  CATPPO_ACT16=0: fp32-stored.
+  static const int act16_fwd = env_int("CATPPO_ACT16", 1);
+  const bool fwd16 = act16_fwd && shape->mfma_bf16 == 1 && shape->n_hidden >= 2 && N >= 4096 && w.w16 != nullptr;
+  if (fwd16) forward_hidden16(shape, L, params, x, N, w, critic_only ? 1 : 2, s, shape->n_hidden, true);
+  else forward_hidden(shape, L, params, x, N, w, 0, critic_only ? 1 : 2, s);
+  if (fwd16) catppo_plan_note(ctx, "rollout forward, %lld rows: bf16-stored activations between the layer-wise launches", (long long)N);
   catppo_plan_note(ctx, "rollout forward, %lld rows: %d layer-wise GEMM launches (gemm_f32_kernel) + head_act_kernel "
                    "[outside the one-launch window %s, or operand precision %d != fp32]", (long long)N, shape->n_hidden,
                    "CATPPO_FUSED_FWD_MIN_ROWS..MAX_ROWS (2049..4096)", shape->mfma_bf16);
@@ -583,45 +589,8 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
     FusedFwdArgs ra{};
     size_t rlds = 0;
     if (act16) {
-      // bf16 copies of W_1 .. W_{nl-1} (as stored and transposed), then the layer-wise forward with bf16-stored activations
-      W16Segs ws16{};
-      int64_t tot = 0;
-      for (int net = 0; net < 2; ++net)
-        for (int l = 1; l < nl; ++l) {
-          const int i = ws16.n++;
-          ws16.off[i] = L.off_w[net][l], ws16.out[i] = shape->hidden[l], ws16.in[i] = L.in_dim[l];
-          ws16.first[i] = tot;
-          tot += (int64_t)shape->hidden[l] * L.in_dim[l];
-        }
-      ws16.first[ws16.n] = tot;
-      for (int l = 0; l < nl - 1; ++l) {
-        Params pf{};
-        pf.xcd_legacy = xcd_legacy();
-        pf.nets = 2, pf.splits = 1;
-        pf.I = (int)M, pf.J = shape->hidden[l];
-        pf.ldc = shape->hidden[l];                           // bf16 elements
-        for (int net = 0; net < 2; ++net) {
-          pf.op[net].bias = params + L.off_b[net][l];
-          pf.op[net].C = w.H[net][l];
-          if (l == 0) {
-            pf.op[net].A = w.xmb, pf.op[net].B = params + L.off_w[net][0];
-          } else {
-            pf.op[net].A = w.H[net][l - 1];
-            pf.op[net].B = reinterpret_cast<const float*>(w.w16 + L.off_w[net][l]);
-          }
-        }
-        if (l == 0) {                                        // fp32-stored operands (observations, W_0), bf16-stored output
-          pf.Kc = L.in_dim[0], pf.lda = L.in_dim[0], pf.ldb = L.in_dim[0];
-          const int n_conv = (int)((cdiv64(tot, 256) + 7) / 8 * 8), t0 = tiles_of<64, 64>(pf);
-          constexpr size_t lds0 = gemm::smem_bytes<64, 64, true, true>();
-          hipLaunchKernelGGL(fwd0_w16_kernel, dim3((unsigned)(n_conv + t0 * 2)), dim3(256), lds0, s, pf, n_conv, t0, params, w.w16,
-                             w.w16t, ws16);
-        } else {                                             // bf16-stored operands: contraction sizes in FLOAT units
-          pf.Kc = L.in_dim[l] / 2, pf.lda = L.in_dim[l] / 2, pf.ldb = L.in_dim[l] / 2;
-          if (pf.J >= 128 && L.in_dim[l] >= 256) launch_gemm_prec<128, 128, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
-          else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);      // (64x64 for a wide layer: measured 0.8 us slower)
-        }
-      }
+      // bf16 copies of W_1 .. W_{nl-1} (as stored and transposed) + the layer-wise forward with bf16-stored activations
+      const int64_t tot = forward_hidden16(shape, L, params, w.xmb, M, w, 2, s, nl - 1, false);
       catppo_plan_note(ctx, "minibatch %lld rows, bf16-stored activations: fwd0_w16_kernel (layer 0 + %lld weights as bf16, stored + "
                        "transposed, in one launch) + %d layer-wise forward GEMM launch(es) on bf16-stored operands", (long long)M,
                        (long long)tot, nl - 2);

@@ -121,7 +121,7 @@ bool carve(const catppo_mlp_shape* s, const catppo_mlp_layout& L, int64_t M, boo
     w->head_s = (float*)take(sizeof(float) * nbh * head_scalars(A));
   }
   w->norm_part = (double*)take(sizeof(double) * kNormSlots);
-  if (training && s->mfma_bf16 == 1) {
+  if (s->mfma_bf16 == 1) {        // (the rollout forward uses the as-stored copy only; one layout keeps the carving simple)
     w->w16 = (uint16_t*)take(sizeof(uint16_t) * L.n_flat);
     w->w16t = (uint16_t*)take(sizeof(uint16_t) * L.n_flat);
   }

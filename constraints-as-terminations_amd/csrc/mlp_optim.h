@@ -198,3 +198,58 @@ __global__ __launch_bounds__(256) void fwd0_w16_kernel(const gemm::Params p, con
   const gemm::TileId id = gemm::xcd_tile_of(b - n_conv, tiles, (gridDim.x - n_conv) / tiles, p.xcd_legacy);
   gemm::gemm_body<64, 64, true, true, gemm::EPI_BIAS_ELU, gemm::BK, 4>(p, id.tile, id.bz, smem);
 }
+
+// Layer-wise forward of hidden layers 0 .. n_layers - 1 with bf16-STORED activations (gemm_f32.h "act16"), `nets` networks from
+// network 0: the first layer's launch also makes the bf16 weight copies of layers 1 .. nl - 1 (stored + transposed) that
+// every later launch of the step reads.  last_fp32: the last of these layers writes fp32 (a consumer that reads fp32
+// activations follows: head_act_kernel of the rollout forward).  Returns the number of weights converted.
+int64_t forward_hidden16(const catppo_mlp_shape* sh, const catppo_mlp_layout& L, const float* params, const float* x, int64_t M,
+                         const MlpWs& w, int nets, hipStream_t s, int n_layers, bool last_fp32) {
+  const int nl = sh->n_hidden;
+  W16Segs ws16{};
+  int64_t tot = 0;
+  for (int net = 0; net < nets; ++net)
+    for (int l = 1; l < nl; ++l) {
+      const int i = ws16.n++;
+      ws16.off[i] = L.off_w[net][l], ws16.out[i] = sh->hidden[l], ws16.in[i] = L.in_dim[l];
+      ws16.first[i] = tot;
+      tot += (int64_t)sh->hidden[l] * L.in_dim[l];
+    }
+  ws16.first[ws16.n] = tot;
+  for (int l = 0; l < n_layers; ++l) {
+    Params pf{};
+    pf.xcd_legacy = xcd_legacy();
+    pf.nets = nets, pf.splits = 1;
+    pf.I = (int)M, pf.J = sh->hidden[l];
+    pf.ldc = sh->hidden[l];                           // bf16 or fp32 elements
+    for (int net = 0; net < nets; ++net) {
+      pf.op[net].bias = params + L.off_b[net][l];
+      pf.op[net].C = w.H[net][l];
+      if (l == 0) {
+        pf.op[net].A = x, pf.op[net].B = params + L.off_w[net][0];
+      } else {
+        pf.op[net].A = w.H[net][l - 1];
+        pf.op[net].B = reinterpret_cast<const float*>(w.w16 + L.off_w[net][l]);
+      }
+    }
+    const bool out32 = last_fp32 && l == n_layers - 1;
+    if (l == 0) {                                        // fp32-stored operands (observations, W_0), bf16-stored output
+      pf.Kc = L.in_dim[0], pf.lda = L.in_dim[0], pf.ldb = L.in_dim[0];
+      const int n_conv = (int)((cdiv64(tot, 256) + 7) / 8 * 8), t0 = tiles_of<64, 64>(pf);
+      constexpr size_t lds0 = gemm::smem_bytes<64, 64, true, true>();
+      hipLaunchKernelGGL(fwd0_w16_kernel, dim3((unsigned)(n_conv + t0 * nets)), dim3(256), lds0, s, pf, n_conv, t0, params, w.w16,
+                         w.w16t, ws16);
+    } else {                                             // bf16-stored operands: contraction sizes in FLOAT units
+      pf.Kc = L.in_dim[l] / 2, pf.lda = L.in_dim[l] / 2, pf.ldb = L.in_dim[l] / 2;
+      const bool big = pf.J >= 128 && L.in_dim[l] >= 256;
+      if (out32) {
+        if (big) launch_gemm_prec<128, 128, true, true, gemm::EPI_BIAS_ELU, 6>(pf, s);
+        else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 6>(pf, s);
+      } else {
+        if (big) launch_gemm_prec<128, 128, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);
+        else launch_gemm_prec<64, 64, true, true, gemm::EPI_BIAS_ELU, 3>(pf, s);      // (64x64 for a wide layer: measured 0.8 us slower)
+      }
+    }
+  }
+  return tot;
+}
