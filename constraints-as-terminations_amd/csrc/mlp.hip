@@ -148,10 +148,8 @@ bool rows_fwd_launch_train(const FusedFwdArgs& fa, size_t lds, int64_t rows, int
   const int64_t tiles = cdiv64(rows, 64);
   // enough row tiles to fill the chip: one workgroup walks both networks (one round of workgroups, the observation
   // tile of a row block fetched by one CU); fewer: one workgroup per (tile, network)
-  static const int force_nets = env_int("CATPPO_ROWS_NETS", 0);       // A/B: 1 = always one network per workgroup
-  static const int store_policy = env_int("CATPPO_ROWS_STORE", 0);
-  a.nets_per_wg = force_nets ? force_nets : (tiles >= n_cu ? 2 : 1);
-  a.store_policy = store_policy;
+  a.nets_per_wg = tiles >= n_cu ? 2 : 1;
+  a.store_policy = 0;
   const int nl = a.n_hidden;
   if (a.nets_per_wg == 2) {
     if (nl == 1) rows_fwd_launch_k<64, true, 2, 1>(a, lds, tiles, 2, s);
@@ -237,8 +235,7 @@ bool rows_wide_dispatch(const FusedFwdArgs& a, size_t lds, int64_t tiles, int ne
 bool rows_wide_launch_train(const FusedFwdArgs& fa, size_t lds, int nch, int64_t rows, int n_cu, hipStream_t s) {
   FusedFwdArgs a = fa;
   const int64_t tiles = cdiv64(rows, 64);
-  static const int force_nets = env_int("CATPPO_ROWS_NETS", 0);
-  a.nets_per_wg = force_nets ? force_nets : (tiles >= n_cu ? 2 : 1);
+  a.nets_per_wg = tiles >= n_cu ? 2 : 1;
   if (a.nets_per_wg == 2) return rows_wide_dispatch<64, true, 2>(a, lds, tiles, 2, nch, s);
   return rows_wide_dispatch<64, true, 1>(a, lds, tiles, 2, nch, s);
 }
@@ -773,7 +770,7 @@ int minibatch_grad_core(catppo_ctx* ctx, const catppo_mlp_shape* shape, const ca
       // split for ~512 workgroups with at least 128 contraction rows each.  At 2048 samples the old rule cut a
       // 256x512 layer into 2048 workgroups of 64 rows - four slabs of work between a prologue and a 33 MB partial store.
       const int t64 = ((out + 63) / 64) * ((in + 63) / 64) * 2;
-      static const int target_wg = env_int("CATPPO_DW_TARGET_WG", 512);      // A/B: workgroups a 64x64-tile weight gradient aims for
+      constexpr int target_wg = 512;      // workgroups a 64x64-tile weight gradient aims for (256 / 384 / 1024 measured: profiles/r6_ab_dw_target.txt)
       splits = target_wg / (t64 > 0 ? t64 : 1);
       const int max128 = (int)(M / 128);
       if (splits > max128) splits = max128;

@@ -136,11 +136,8 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// CATPPO_XCD_LEGACY=1: the round-2 workgroup -> tile order (A/B of the launch-wide XCD mapping, see gemm::xcd_tile_of)
-static int xcd_legacy() {
-  static const int v = env_int("CATPPO_XCD_LEGACY", 0);
-  return v;
-}
+// Params::xcd_legacy = 1 is the round-2 workgroup -> tile order (gemm::xcd_tile_of); its A/B switch went with round 6's prune
+static int xcd_legacy() { return 0; }
 
 // fp32 launch with a wider contraction slab (latency-bound small-M launches: fewer global round trips per tile)
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI, int BKT>
@@ -154,16 +151,9 @@ void launch_gemm_bk(const Params& p, hipStream_t s) {
 }
 
 template <int BM, int BN, bool A_KC, bool B_KC, int EPI>
-void launch_gemm(const Params& p, hipStream_t s, int prec, size_t lds_pad = 0) {
+void launch_gemm(const Params& p, hipStream_t s, int prec) {
   dim3 grid(((p.J + BN - 1) / BN) * ((p.I + BM - 1) / BM), 1, p.nets * p.splits);   // 1-D tile index, see kernel
-  const size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>() + lds_pad;
-  if (lds_pad && prec == 0) {   // residency experiment (CATPPO_FWD_LDS_PAD): fp32 forward GEMMs only
-    auto kern = gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI>;
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    kern<<<grid, dim3(256), lds, s>>>(p);
-    return;
-  }
+  const size_t lds = gemm::smem_bytes<BM, BN, A_KC, B_KC>();
   if (prec == 2)
     gemm::gemm_f32_kernel<BM, BN, A_KC, B_KC, EPI, gemm::BK, 2><<<grid, dim3(256), lds, s>>>(p);
   else if (prec == 1)
@@ -182,38 +172,14 @@ void launch_gemm_auto(const Params& p, hipStream_t s, int prec) {
   // weight gradients pick their split count to fill the chip, so only the shape matters there
   const bool use_big = EPI != gemm::EPI_MUL_DELU && p.I >= 128 && p.J >= 128 && kc >= 256 &&
                        (EPI == gemm::EPI_PARTIAL || big >= 384);
-  if constexpr (EPI == gemm::EPI_BIAS_ELU) {
-    // experiment hooks (A/B on the GPU box): CATPPO_FWD_TILE = 64x64 | 64x128 | 128x64, CATPPO_FWD_LDS_PAD = bytes of
-    // unused LDS per workgroup (caps the number of resident workgroups per CU => the grid runs in several rounds)
-    static const int tile_sel = [] {
-      const char* e = getenv("CATPPO_FWD_TILE");
-      if (!e) return 0;
-      if (!strcmp(e, "64x64")) return 1;
-      if (!strcmp(e, "64x128")) return 2;
-      if (!strcmp(e, "128x64")) return 3;
-      return 0;
-    }();
-    static const size_t pad = [] {
-      const char* e = getenv("CATPPO_FWD_LDS_PAD");
-      return e ? (size_t)atol(e) : (size_t)0;
-    }();
-    if (use_big && (tile_sel || pad)) {
-      if (tile_sel == 1) launch_gemm<64, 64, A_KC, B_KC, EPI>(p, s, prec, pad);
-      else if (tile_sel == 2) launch_gemm<64, 128, A_KC, B_KC, EPI>(p, s, prec, pad);
-      else if (tile_sel == 3) launch_gemm<128, 64, A_KC, B_KC, EPI>(p, s, prec, pad);
-      else launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, prec, pad);
-      return;
-    }
-  }
   if (use_big) {
     launch_gemm<128, 128, A_KC, B_KC, EPI>(p, s, prec);
     return;
   }
   if constexpr (EPI != gemm::EPI_PARTIAL) {
-    static const int small_bk = env_int("CATPPO_SMALL_BK", 64);      // 16 | 32 | 64, see kSmallRows
-    if (prec == 0 && small_bk > 16 && p.I <= kSmallRows && p.Kc % small_bk == 0 && p.Kc >= 2 * small_bk) {
-      if (small_bk == 32) launch_gemm_bk<64, 64, A_KC, B_KC, EPI, 32>(p, s);
-      else launch_gemm_bk<64, 64, A_KC, B_KC, EPI, 64>(p, s);
+    constexpr int small_bk = 64;      // see kSmallRows (32-wide slabs measured in between, round 2)
+    if (prec == 0 && p.I <= kSmallRows && p.Kc % small_bk == 0 && p.Kc >= 2 * small_bk) {
+      launch_gemm_bk<64, 64, A_KC, B_KC, EPI, 64>(p, s);
       return;
     }
   }
@@ -278,9 +244,9 @@ void launch_pair_tiles(const Params& pw, const Params& px, hipStream_t s, int pr
 // every contraction slab costs a full global round trip.  There the weight gradient runs on 64x64 tiles (4x the
 // workgroups of the 128x128 choice: 2048 rows, 256x512 layer: 35 -> 27 us for the pair) and the forward GEMMs walk
 // the contraction in 64-wide slabs (4x fewer round trips; 112 -> 100 us per optimiser step together; measured with
-// CATPPO_DW_SMALL_TILE / CATPPO_SMALL_BK, which remain as switches).
+// switches that went with round 6's prune).
 void launch_dw_dx_pair(const Params& pw, const Params& px, hipStream_t s, int prec, int n_cu = 256) {
-  static const int small_tile = env_int("CATPPO_DW_SMALL_TILE", 1);
+  constexpr int small_tile = 1;
   // Round 5: a weight gradient whose 128x128 tiling yields fewer long workgroups than there are CUs (a 128-wide layer - the
   // reference's last hidden layer: 2 tiles x 2 networks x 32 splits = 128 on 256 CUs) takes 64x64 tiles instead (512
   // shorter workgroups, same splits, same contraction order per element: bit-identical): the reference's layer-2 pair
