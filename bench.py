@@ -742,12 +742,15 @@ def main():
             # minibatch group = a layer-wise step that moves every tensor once each way: the gathered
             # inputs, every hidden activation written and read back, every dZ above the first layer written and read back.
             hid = list(w["hidden"])
-            act_b = M * sum(hid) * 4 * 2
-            dz_b = M * sum(hid[1:]) * 4 * 2
+            # round 6: hidden activations and dZ are STORED as bf16 from 4096-row minibatches up (csrc/gemm_f32.h "act16")
+            el = 2 if (M >= 4096 and os.environ.get("CATPPO_ACT16", "1") != "0") else 4
+            act_b = M * sum(hid) * el * 2
+            dz_b = M * sum(hid[1:]) * el * 2
             alg_bytes = 2 * act_b + 2 * dz_b + M * (trainer.Dp + trainer.A + 4) * 4
             mf = out["roofline"]
             out["roofline"] = {"bound": "hbm", "kernel": mf["kernel"], "achieved": alg_bytes / grad_us / 1e3, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": alg_bytes / grad_us / 1e3 / HBM_PEAK_GBPS, "algorithmic_bytes": alg_bytes,
+                               "activation_element_bytes": el,
                                "traffic": traffic, "traffic_GBps": None if not traffic else traffic / grad_us / 1e3,
                                "hbm_frac": None if not traffic else traffic / grad_us / 1e3 / HBM_PEAK_GBPS,
                                "avg_launch_us": grad_us, "launches_timed": n_timed, "timed": mf["timed"],

@@ -12,7 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel", "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel", "step16_kernel", "dw_multi_kernel")
+GROUP = ("gemm_f32_kernel", "gemm_pair_kernel", "head_loss_kernel", "fwd_head_kernel", "seg_reduce_kernel", "rows_fwd_kernel", "dw_fold_kernel", "rows_fwd_wide_kernel", "step16_kernel", "dw_multi_kernel", "fwd0_w16_kernel")
 
 
 def per_launch(path):
@@ -25,8 +25,14 @@ def per_launch(path):
         s, calls = float(r["sum"]), int(r["calls"])
         if "<64, 64, true, true, 0, 64" in r["kernel"] or "rows_fwd_kernel<32" in r["kernel"] or "rows_fwd_wide_kernel<32" in r["kernel"]:
             continue                    # 64-wide contraction slabs: the rollout's policy GEMMs only (<= 4096 rows)
+        if r["kernel"].rstrip().split("(")[0].endswith(", 6>"):
+            continue                    # bf16-stored input, fp32 output: the rollout forward's last hidden layer only
         if "<64, 64, true, true, 0" in r["kernel"]:
             s = s / calls * n_mb        # 64x64 forward launches also serve the rollout: one (K=Dp layer) per minibatch
+        elif "fwd0_w16_kernel" in r["kernel"] or ("gemm_f32_kernel<" in r["kernel"] and "true, true, 0, 16" in r["kernel"]):
+            # layer-wise forward launches of the bf16-operand mode serve the rollout too (a few calls per env step against
+            # hundreds per update phase): whole launches per minibatch x the average call
+            s = s / calls * max(1, round(calls / n_mb)) * n_mb
         kib += s
         detail[r["kernel"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-70:]] = \
             round(float(r["avg"]), 1)
