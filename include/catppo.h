@@ -255,7 +255,10 @@ typedef struct catppo_mlp_shape {
   int32_t mfma_bf16;                /* 0: fp32-input MFMA (reference numerics, default).  1: the hidden-layer GEMMs
                                        (forward, data gradient, weight gradient) round their operands to bf16
                                        (RNE) and use v_mfma_f32_32x32x16_bf16 with fp32 accumulation; parameters,
-                                       activations, gradients and the optimiser stay fp32 (BASELINE config 5).
+                                       gradients and the optimiser stay fp32 (BASELINE config 5).  Round 6: from 4096 rows
+                                       up the hidden activations and dZ live in the workspace AS bf16 (rounded where they
+                                       are produced instead of where a GEMM consumes them: same operands; elu' and the bias
+                                       gradients see the rounded values) - CATPPO_ACT16=0 keeps them fp32-stored.
                                        2: split-bf16 ("bf16x3"): every operand is split x = hi + lo (two bf16 values,
                                        16 mantissa bits) and a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on the bf16
                                        matrix pipe - meets the fp32 parity tolerances at 5x less matrix-pipe time;
