@@ -635,6 +635,10 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   float dbsum = 0.0f;  // EPI_PARTIAL: column sum of A for output row i0+tid (tid < BM)
+  constexpr int DBC = (EPI == EPI_PARTIAL && !A_KC) ? 256 / BM : 1, DBU = (EPI == EPI_PARTIAL && !A_KC) ? 4 / DBC : 1;   // column copies, quarters per thread
+  static_assert(!(EPI == EPI_PARTIAL && !A_KC) || BM == 64 || BM == 128, "bias-gradient quarters: 64- or 128-row weight-gradient tiles");
+  [[maybe_unused]] float dbp[DBU] = {};
+  [[maybe_unused]] const int db_col = tid % BM, db_c = tid / BM;
   const bool do_db = (EPI == EPI_PARTIAL) && op.dbias != nullptr && j0 == 0;
 
   const int n_slabs = (k_end - k_begin + BK - 1) / BK;
@@ -694,10 +698,20 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
     const float* a = As + cur * A_TILE;
     const float* b = Bs + cur * B_TILE;
 
-    if (EPI == EPI_PARTIAL) {
-      if (do_db && tid < BM) {
+    if constexpr (EPI == EPI_PARTIAL && !A_KC) {
+      if (do_db) {                                 // workgroup-uniform
+        // Bias gradient = column sums of A over the split.  Round 6: ALL 256 threads take part - thread (column db_col, copy
+        // db_c) sums its quarter(s) of the slab's k rows into its own running partial(s) - instead of the first BM threads
+        // walking all BK rows while the other waves wait for them at the slab's barrier (16 dependent LDS reads + adds per
+        // slab on the critical path of a workgroup whose matrix work is 8 instructions per wave).  The four quarter sums are
+        // combined in a fixed order behind the loop: (q0 + q1) + (q2 + q3), the same for every tile height.  Update phase 8.957 ->
+        // 8.936 ms at cfg2, 11.327 -> 11.266 ms at the reference shapes (three interleaved rounds, profiles/r6_ab_db_spread.txt).
 #pragma unroll
-        for (int kk = 0; kk < BK; ++kk) dbsum += a[kk * BM + tid];  // A is I-contig here
+        for (int u = 0; u < DBU; ++u) {
+          const int g = db_c * DBU + u;
+#pragma unroll
+          for (int kk = 0; kk < BK / 4; ++kk) dbp[u] += a[(g * (BK / 4) + kk) * BM + db_col];
+        }
       }
     }
 
@@ -875,6 +889,15 @@ __device__ __forceinline__ void gemm_body(const Params& p, const int wg, const i
   } else {
     if (kPipedLoop && interior && (k_end - k_begin) % BK == 0) main_loop(std::true_type{});
     else main_loop(std::false_type{});
+    if constexpr (EPI == EPI_PARTIAL && !A_KC) {
+      if (do_db) {                                 // workgroup-uniform; the slab buffers are free behind the loop's last barrier
+#pragma unroll
+        for (int u = 0; u < DBU; ++u) smem[(db_c * DBU + u) * BM + db_col] = dbp[u];
+        __syncthreads();
+        if (tid < BM) dbsum = (smem[tid] + smem[BM + tid]) + (smem[2 * BM + tid] + smem[3 * BM + tid]);
+        __syncthreads();
+      }
+    }
   }
 
 #ifdef GEMM_TIMELINE
