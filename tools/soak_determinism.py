@@ -35,8 +35,13 @@ def run(workload, iters):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 100
+    argv = sys.argv[1:]
+    iters = 100
+    if "--iters" in argv:
+        i = argv.index("--iters")
+        iters = int(argv[i + 1])
+        del argv[i:i + 2]
+    args = [a for a in argv if not a.startswith("--")]
     rc = 0
     for wl in (args or ["cfg3_shard", "cfg5", "cfg1", "cfg2"]):
         with contextlib.redirect_stdout(sys.stderr):
