@@ -364,3 +364,36 @@ def test_native_comm_known_answer_pass_holds_for_any_world_size(world):
     [t.start() for t in th]
     [t.join(120) for t in th]
     assert all(isinstance(x, str) and "SUM fp32" in x and "SUM fp64" in x for x in res), res
+
+
+def test_branch_flip_machinery_on_synthetic_traces():
+    """The analysis the whole-iteration GPU tests lean on when parameters leave the tight bar (smoke_impl.first_parting_step /
+    analyse_branches, cleanrl/ppo.py:320-341), on hand-made data: the parting step is where the distance LEAVES its
+    rounding-level plateau (not the first step above the bar), a flipped sample is one whose device clip code differs from the
+    code of the oracle's own ratio / value difference, and its margin is the oracle's distance to the boundary."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import smoke_impl
+    bar = 1.2e-5
+    assert smoke_impl.first_parting_step([7e-8] * 5 + [9e-7, 1.6e-6, 2.4e-6, 1.3e-5], bar) == 5      # two-rank cfg3 shape
+    assert smoke_impl.first_parting_step([6e-8] * 9 + [1.0e-5, 2.0e-5], bar) == 9                     # cfg4: one jump
+    assert smoke_impl.first_parting_step([1e-8] * 4, bar) is None
+    assert smoke_impl.first_parting_step([5e-8, 2e-5], bar) == 1
+    assert smoke_impl.first_parting_step([3e-5, 4e-5], bar) == 0                                      # apart from the first step
+    clip = 0.2
+    # four samples: inside, just above 1 + clip (oracle), below 1 - clip, inside; the device has sample 1 INSIDE
+    ratio_o = torch.tensor([1.0, 1.2 + 3e-7, 0.7, 1.1])
+    ratio_d = torch.tensor([1.0, 1.2 - 2e-7, 0.7, 1.1])
+    new_o, old_o, ret_o = torch.tensor([0.0, 0.5, -0.3, 0.1]), torch.zeros(4), torch.tensor([0.1, 0.2, 0.0, 0.0])
+    dl_d = new_o - old_o
+    code = lambda v, c: ((v < c - clip).long() + 2 * (v > c + clip).long())
+    e1, e2 = new_o - ret_o, old_o + (new_o - old_o).clamp(-clip, clip) - ret_o
+    vmax = ((e1 * e1 > e2 * e2).long() + 2 * (e1 * e1 < e2 * e2).long()) << 2
+    codes = torch.cat([code(ratio_d, 1.0), code(dl_d, 0.0) | vmax])
+    step = dict(ratio=ratio_o, newvalue_n=new_o, old_values_n=old_o, returns_n=ret_o)
+    rep = smoke_impl.analyse_branches(codes, ratio_d, dl_d, step, clip, True)
+    assert rep["flipped_surrogate"] == 1 and rep["flipped_value"] == 0, rep
+    assert abs(rep["max_margin_of_flipped"] - abs(abs(float(ratio_o[1]) - 1.0) - clip)) < 2e-8 and rep["max_margin_of_flipped"] < 1e-6
+    assert abs(rep["max_device_oracle_ratio_diff"] - abs(float(ratio_o[1] - ratio_d[1]))) < 2e-8
+    # no disagreement -> nothing flipped, no margin
+    rep0 = smoke_impl.analyse_branches(torch.cat([code(ratio_o, 1.0), code(dl_d, 0.0) | vmax]), ratio_o, dl_d, step, clip, True)
+    assert rep0["flipped_surrogate"] == 0 and rep0["flipped_value"] == 0 and rep0["max_margin_of_flipped"] is None
