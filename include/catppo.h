@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CATPPO_VERSION 600 /* 0.6.0: the _ex families collapsed into one entry each (59 exports, 77 in 0.5); the
+#define CATPPO_VERSION 600 /* 0.6.0: the _ex families collapsed into one entry each (58 exports, 77 in 0.5); the
                               names of ABI <= 0.5 are static inline wrappers in catppo_compat.h */
 
 #define CATPPO_OK 0
